@@ -1,0 +1,587 @@
+"""numpy restatement of the reference's sampling + decode path (CPU oracle).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): the checker for the HIP path and
+the `cpu_baseline` of bench.py.  Never imported by the product package.
+
+Parity status: PINNED by goldens generated here from the reference itself
+(tests/golden/make_goldens.py imports /root/reference on CPU, fp32 + bf16,
+torch 2.10.0 ATen kernels) - the reference ships no tests/known-answer vectors
+(SURVEY.md §4, §8c).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  fp32 math unless `dt='bf16'`, in which case tensors are
+rounded to bfloat16 at the points where the reference's bf16 modules would
+materialise a bf16 tensor (dtype ladder).
+"""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------
+# dtype emulation
+# ----------------------------------------------------------------------------
+def bf16_round(x):
+    """float32 -> nearest-even bfloat16, returned as float32."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    out = ((u + r) & np.uint32(0xFFFF0000)).view(F32)
+    return np.where(np.isfinite(x), out, x).astype(F32)
+
+
+def rt(x, dt):
+    return bf16_round(x) if dt == "bf16" else np.asarray(x, dtype=F32)
+
+
+def find_multiple(n, k):
+    return n if n % k == 0 else n + k - (n % k)
+
+
+# ----------------------------------------------------------------------------
+# RoPE tables  (autoregressive/models/gpt.py:407-420, gpt_video.py:532-552)
+# ----------------------------------------------------------------------------
+def rope_table_2d(grid, n_elem, base=10000.0, cls_token_num=120):
+    half = n_elem // 2
+    ar = np.arange(0, half, 2)[: half // 2].astype(F32)
+    freqs = (F32(1.0) / (F32(base) ** (ar / F32(half)))).astype(F32)
+    t = np.arange(grid).astype(F32)
+    fr = np.outer(t, freqs).astype(F32)                       # [g, half/2]
+    fg = np.concatenate([np.broadcast_to(fr[:, None, :], (grid, grid, fr.shape[1])),
+                         np.broadcast_to(fr[None, :, :], (grid, grid, fr.shape[1]))], axis=-1)
+    cache = np.stack([np.cos(fg), np.sin(fg)], axis=-1).astype(F32).reshape(grid * grid, -1, 2)
+    return np.concatenate([np.zeros((cls_token_num, n_elem // 2, 2), F32), cache], axis=0)
+
+
+def rope_table_3d(grid, vae_t, n_elem, base=10000.0, cls_token_num=120):
+    # gpt_video.py:547-549: the 2-D table tiled vae_t times, no temporal term (Q3)
+    t2 = rope_table_2d(grid, n_elem, base, 0)
+    rep = np.tile(t2[None], (vae_t, 1, 1, 1)).reshape(vae_t * grid * grid, -1, 2)
+    return np.concatenate([np.zeros((cls_token_num, n_elem // 2, 2), F32), rep], axis=0)
+
+
+def apply_rope(x, fc, dt):
+    """x [B,q,H,hd]; fc [q,hd/2,2]  (gpt.py:423-433): adjacent pairs, fp32 then cast."""
+    xs = x.astype(F32).reshape(*x.shape[:-1], -1, 2)
+    c = fc[None, :, None, :, 0]
+    s = fc[None, :, None, :, 1]
+    o = np.stack([xs[..., 0] * c - xs[..., 1] * s, xs[..., 1] * c + xs[..., 0] * s], axis=-1)
+    return rt(o.reshape(x.shape), dt)
+
+
+# ----------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------
+def linear(x, w, dt, b=None):
+    y = x.astype(F32) @ w.T.astype(F32)
+    if b is not None:
+        y = y + b
+    return rt(y, dt)
+
+
+def rmsnorm(x, w, eps, dt):
+    # gpt.py:143-148: fp32 normalise -> cast -> * weight
+    xf = x.astype(F32)
+    n = xf * (F32(1.0) / np.sqrt(np.mean(xf * xf, axis=-1, keepdims=True, dtype=F32) + F32(eps)))
+    return rt(rt(n, dt) * w, dt)
+
+
+def silu(x):
+    x = x.astype(F32)
+    return x / (F32(1.0) + np.exp(-x))
+
+
+def gelu_tanh(x):
+    x = x.astype(F32)
+    k = F32(math.sqrt(2.0 / math.pi))
+    return F32(0.5) * x * (F32(1.0) + np.tanh(k * (x + F32(0.044715) * x * x * x)))
+
+
+def softmax_lastdim(x):
+    x = x.astype(F32)
+    m = np.max(x, axis=-1, keepdims=True)
+    e = np.exp(x - m)
+    return (e / np.sum(e, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# GPT  (autoregressive/models/gpt.py:262-371; t2v: gpt_video.py:270-431,
+#       gpt_video_diff.py:615-661)
+# ----------------------------------------------------------------------------
+class GPTOracle:
+    """cfg keys: dim,n_layer,n_head,vocab_size,block_size,cls_token_num,model_type
+    ('c2i'|'t2i'|'t2v'), num_classes, caption_dim, norm_eps, rope_base,
+    vae_embed_dim,num_frames,t_downsample_size, head ('logits'|'adapter2'|'hidden')."""
+
+    def __init__(self, cfg, sd, dt="fp32"):
+        self.cfg = dict(cfg)
+        self.dt = dt
+        self.sd = {k: rt(v, dt) for k, v in sd.items()}
+        c = self.cfg
+        self.D = c["dim"]
+        self.H = c["n_head"]
+        self.hd = self.D // self.H
+        self.L = c["n_layer"]
+        self.eps = c.get("norm_eps", 1e-5)
+        self.model_type = c["model_type"]
+        self.cls = c["cls_token_num"]
+        self.head = c.get("head", "logits" if self.model_type != "t2v" else "adapter2")
+        self.grid = int(round(c["block_size"] ** 0.5))
+        assert self.grid * self.grid == c["block_size"]
+        self.num_classes = c.get("num_classes", 1000)
+
+    def rope_table(self):
+        c = self.cfg
+        if self.model_type == "t2v":
+            vae_t = (c["num_frames"] - 1) // c["t_downsample_size"] + 1
+            return rope_table_3d(self.grid, vae_t, self.hd, c.get("rope_base", 10000.0), self.cls)
+        return rope_table_2d(self.grid, self.hd, c.get("rope_base", 10000.0), self.cls)
+
+    def setup_caches(self, bsz, max_seq):
+        # gpt.py:318-332
+        S = find_multiple(max_seq, 8)
+        self.S = S
+        self.k_cache = np.zeros((self.L, bsz, self.H, S, self.hd), F32)
+        self.v_cache = np.zeros((self.L, bsz, self.H, S, self.hd), F32)
+        self.causal_mask = np.tril(np.ones((S, S), bool))[None].repeat(bsz, 0)
+        self.freqs = self.rope_table()
+
+    # -- embeddings ---------------------------------------------------------
+    def embed_cond(self, cond):
+        sd, dt = self.sd, self.dt
+        if self.model_type == "c2i":
+            return sd["cls_embedding.embedding_table.weight"][cond][:, None, :]      # gpt.py:82
+        h = linear(rt(cond, dt), sd["cls_embedding.cap_proj.fc1.weight"], dt)           # gpt.py:127-131
+        h = rt(gelu_tanh(h), dt)
+        return linear(h, sd["cls_embedding.cap_proj.fc2.weight"], dt)[:, : self.cls]
+
+    def embed_tokens(self, idx):
+        return self.sd["tok_embeddings.weight"][idx]                                     # gpt.py:354
+
+    def embed_latent(self, lat):
+        sd, dt = self.sd, self.dt                                                        # gpt_video.py:410
+        h = linear(rt(lat, dt), sd["vae_latent_adapter.fc1.weight"], dt)
+        h = rt(gelu_tanh(h), dt)
+        return linear(h, sd["vae_latent_adapter.fc2.weight"], dt)
+
+    # -- transformer --------------------------------------------------------
+    def _attention(self, li, x, fc, input_pos, mask):
+        sd, dt, H, hd, D = self.sd, self.dt, self.H, self.hd, self.D
+        B, q, _ = x.shape
+        qkv = linear(x, sd[f"layers.{li}.attention.wqkv.weight"], dt)                    # gpt.py:215
+        xq, xk, xv = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        xq = apply_rope(xq.reshape(B, q, H, hd), fc, dt)
+        xk = apply_rope(xk.reshape(B, q, H, hd), fc, dt)
+        xv = xv.reshape(B, q, H, hd)
+        xq, xk, xv = (t.transpose(0, 2, 1, 3) for t in (xq, xk, xv))
+        self.k_cache[li][:B, :, input_pos] = xk                                          # gpt.py:177-185
+        self.v_cache[li][:B, :, input_pos] = xv
+        keys, vals = self.k_cache[li][:B], self.v_cache[li][:B]
+        sc = np.einsum("bhqd,bhsd->bhqs", xq.astype(F32), keys) * F32(1.0 / math.sqrt(hd))  # gpt.py:233
+        sc = np.where(mask[:, None], sc, F32(-np.inf))
+        p = softmax_lastdim(sc)
+        o = rt(np.einsum("bhqs,bhsd->bhqd", p, vals), dt)
+        o = o.transpose(0, 2, 1, 3).reshape(B, q, D)
+        return linear(o, sd[f"layers.{li}.attention.wo.weight"], dt)
+
+    def _ffn(self, li, x):
+        sd, dt = self.sd, self.dt                                                        # gpt.py:166-167
+        a = linear(x, sd[f"layers.{li}.feed_forward.w1.weight"], dt)
+        b = linear(x, sd[f"layers.{li}.feed_forward.w3.weight"], dt)
+        g = rt(rt(silu(a), dt) * b, dt)
+        return linear(g, sd[f"layers.{li}.feed_forward.w2.weight"], dt)
+
+    def body(self, h, input_pos):
+        """h [B,q,D] token embeddings; returns normed hidden [B,q,D] (gpt.py:356-370)."""
+        sd, dt = self.sd, self.dt
+        B = h.shape[0]
+        mask = self.causal_mask[:B][:, input_pos]                                        # [B,q,S]
+        fc = self.freqs[input_pos]
+        for li in range(self.L):
+            a = self._attention(li, rmsnorm(h, sd[f"layers.{li}.attention_norm.weight"], self.eps, dt), fc, input_pos, mask)
+            h = rt(h + a, dt)                                                            # gpt.py:257
+            f = self._ffn(li, rmsnorm(h, sd[f"layers.{li}.ffn_norm.weight"], self.eps, dt))
+            h = rt(h + f, dt)                                                            # gpt.py:258
+        return rmsnorm(h, sd["norm.weight"], self.eps, dt)
+
+    def head_out(self, h):
+        sd, dt = self.sd, self.dt
+        if self.head == "logits":
+            return linear(h, sd["output.weight"], dt).astype(F32)                        # gpt.py:371
+        if self.head == "adapter2":                                                      # gpt_video.py:431
+            y = linear(h, sd["vae_latent_adapter2.fc1.weight"], dt)
+            y = rt(gelu_tanh(y), dt)
+            return linear(y, sd["vae_latent_adapter2.fc2.weight"], dt)
+        return h                                                                         # gpt_video_diff.py:657
+
+    def forward(self, idx=None, cond=None, latent=None, input_pos=None):
+        if cond is not None:
+            h = self.embed_cond(cond)
+        elif latent is not None:
+            h = self.embed_latent(latent)
+        else:
+            h = self.embed_tokens(idx)
+        return self.head_out(self.body(rt(h, self.dt), np.asarray(input_pos)))
+
+
+# ----------------------------------------------------------------------------
+# sampler  (autoregressive/models/generate.py:16-66)
+# ----------------------------------------------------------------------------
+def top_k_top_p_filtering(logits, top_k=0, top_p=1.0):
+    logits = np.array(logits, dtype=F32, copy=True)
+    V = logits.shape[-1]
+    if top_k > 0:
+        k = min(max(top_k, 1), V)
+        kth = np.partition(logits, V - k, axis=-1)[..., V - k][..., None]                # generate.py:35
+        logits[logits < kth] = -np.inf                                                   # ties kept (Q5)
+    if top_p < 1.0:
+        order = np.argsort(-logits, axis=-1, kind="stable")
+        sl = np.take_along_axis(logits, order, axis=-1)
+        probs = softmax_lastdim(sl)
+        cum = np.cumsum(probs.astype(np.float64), axis=-1).astype(F32)                   # ATen CPU cumsum: double acc
+        rem = cum > F32(top_p)
+        rem[..., 1:] = rem[..., :-1].copy()                                              # generate.py:48-49
+        rem[..., 0] = False
+        mask = np.zeros_like(rem)
+        np.put_along_axis(mask, order, rem, axis=-1)
+        logits[mask] = -np.inf
+    return logits
+
+
+def sample(logits_last, temperature=1.0, top_k=0, top_p=1.0, sample_logits=True, q=None):
+    """logits_last [B,V] fp32.  q: Exp(1) noise [B,V] (torch.multinomial == argmax(p/q))."""
+    logits = (logits_last.astype(F32) / F32(max(temperature, 1e-5))).astype(F32)
+    if top_k > 0 or top_p < 1.0:
+        logits = top_k_top_p_filtering(logits, top_k, top_p)
+    probs = softmax_lastdim(logits)
+    if sample_logits:
+        assert q is not None
+        idx = np.argmax((probs / q.astype(F32)).astype(F32), axis=-1)
+    else:
+        idx = np.argmax(probs, axis=-1)                                                  # first max (Q6)
+    return idx.astype(np.int64), probs
+
+
+def cfg_combine(x, scale):
+    c, u = np.split(x, 2, axis=0)                                                        # generate.py:81-82
+    return (u + (c - u) * F32(scale)).astype(F32)
+
+
+def build_mask(model, T, emb_masks, cfg_on):
+    """generate.py:156-165 (Q4): zero padded text columns, then force the diagonal."""
+    if emb_masks is None:
+        return
+    m = np.asarray(emb_masks).astype(bool)
+    if cfg_on:
+        m = np.concatenate([m, m], axis=0)
+    model.causal_mask[:, :, :T] = model.causal_mask[:, :, :T] & m[:, None, :]
+    S = model.causal_mask.shape[1]
+    model.causal_mask[:, np.arange(S), np.arange(S)] = True
+
+
+def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1,
+             temperature=1.0, top_k=0, top_p=1.0, sample_logits=True, noise=None, trace=None):
+    """Discrete-token generate (generate.py:127-180).  noise: [N,B,V] Exp(1) or None.
+    trace (optional dict) receives per-step combined logits margins."""
+    cond = np.asarray(cond)
+    cfg_on = cfg_scale > 1.0
+    if model.model_type == "c2i":
+        cc = np.concatenate([cond, np.full_like(cond, model.num_classes)]) if cfg_on else cond
+        T = 1
+    elif model.model_type == "t2i":
+        if cfg_on:
+            null = np.zeros_like(cond) + model.sd["cls_embedding.uncond_embedding"]
+            cc = np.concatenate([cond, null])
+        else:
+            cc = cond
+        T = cond.shape[1]
+    else:
+        raise Exception("please check model type")
+    B = cond.shape[0]
+    Bp = B * 2 if cfg_on else B
+    model.setup_caches(Bp, T + max_new_tokens)
+    build_mask(model, T, emb_masks, cfg_on)
+    seq = np.empty((B, max_new_tokens), np.int32)
+    logits = model.forward(cond=cc, input_pos=np.arange(T))[:, -1]
+    if cfg_on:
+        logits = cfg_combine(logits, cfg_scale)
+    if trace is not None:
+        trace.setdefault("logits", []).append(logits.copy())
+    tok, _ = sample(logits, temperature, top_k, top_p, sample_logits, None if noise is None else noise[0])
+    seq[:, 0] = tok
+    cfg_flag = True
+    for i in range(max_new_tokens - 1):
+        if cfg_interval > -1 and i > cfg_interval:
+            cfg_flag = False
+        x = np.concatenate([tok, tok]) if cfg_on else tok
+        logits = model.forward(idx=x[:, None], input_pos=np.array([T + i]))[:, -1]
+        if cfg_on:
+            logits = cfg_combine(logits, cfg_scale) if cfg_flag else logits[:B]          # generate.py:96-99 (Q7)
+        if trace is not None:
+            trace["logits"].append(logits.copy())
+        tok, _ = sample(logits, temperature, top_k, top_p, sample_logits, None if noise is None else noise[i + 1])
+        seq[:, i + 1] = tok
+    return seq
+
+
+def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1):
+    """Continuous-latent generate with the adapter2 (MSE) head: skeleton of
+    generate_video_diff.py:185-228 with sample() = identity (:57-60) and the head of
+    gpt_video.py:431; CFG combine on the output embeddings as in the commented block
+    generate_video_diff.py:97-105 (the shipped code runs cfg_scale=1 only)."""
+    cfg_on = cfg_scale > 1.0
+    assert model.model_type == "t2v"
+    if cfg_on:
+        null = np.zeros_like(cond) + model.sd["cls_embedding.uncond_embedding"]
+        cc = np.concatenate([cond, null])
+    else:
+        cc = cond
+    T = cond.shape[1]
+    B = cond.shape[0]
+    Bp = B * 2 if cfg_on else B
+    model.setup_caches(Bp, T + max_new_tokens)
+    build_mask(model, T, emb_masks, cfg_on)
+    C = model.cfg["vae_embed_dim"]
+    out = np.empty((B, max_new_tokens, C), F32)
+    e = model.forward(cond=cc, input_pos=np.arange(T))[:, -1]
+    if cfg_on:
+        e = rt(cfg_combine(e, cfg_scale), model.dt)
+    out[:, 0] = e
+    cfg_flag = True
+    for i in range(max_new_tokens - 1):
+        if cfg_interval > -1 and i > cfg_interval:
+            cfg_flag = False
+        x = np.concatenate([e, e]) if cfg_on else e
+        e = model.forward(latent=x[:, None, :], input_pos=np.array([T + i]))[:, -1]
+        if cfg_on:
+            e = rt(cfg_combine(e, cfg_scale), model.dt) if cfg_flag else e[:B]
+        out[:, i + 1] = e
+    return out
+
+
+# ----------------------------------------------------------------------------
+# conv / norm primitives shared by the VQ and CausalVAE decoders
+# ----------------------------------------------------------------------------
+def swish(x):
+    return silu(x)                                                                       # vq_model.py:354-356
+
+
+def group_norm(x, w, b, groups=32, eps=1e-6):
+    """x [B,C,...] (vq_model.py:359-364; normalize.py:14-17)."""
+    B, C = x.shape[:2]
+    xr = x.astype(F32).reshape(B, groups, -1)
+    mean = xr.mean(axis=-1, keepdims=True, dtype=np.float64)
+    var = ((xr - mean) ** 2).mean(axis=-1, keepdims=True, dtype=np.float64)
+    xn = ((xr - mean) / np.sqrt(var + eps)).astype(F32).reshape(x.shape)
+    sh = (1, C) + (1,) * (x.ndim - 2)
+    return (xn * w.reshape(sh) + b.reshape(sh)).astype(F32)
+
+
+def conv2d(x, w, b, pad):
+    """x [B,Cin,H,W], w [Cout,Cin,kh,kw], stride 1, zero pad."""
+    B, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    xp = np.pad(x.astype(F32), ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    Ho, Wo = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
+    out = np.zeros((B, Cout, Ho * Wo), F32)
+    for i in range(kh):
+        for j in range(kw):
+            patch = np.ascontiguousarray(xp[:, :, i:i + Ho, j:j + Wo]).reshape(B, Cin, Ho * Wo)
+            out += np.einsum("oc,bcn->bon", w[:, :, i, j].astype(F32), patch, optimize=True)
+    out = out.reshape(B, Cout, Ho, Wo)
+    if b is not None:
+        out += b.reshape(1, -1, 1, 1)
+    return out
+
+
+def causal_conv3d(x, w, b, pad_hw):
+    """CausalConv3d (conv.py:76-130): replicate frame 0 (k_t-1)x in front, zero-pad H/W
+    by pad_hw, time padding forced to 0 (Q13).  x [B,Cin,T,H,W], w [Cout,Cin,kt,kh,kw]."""
+    B, Cin, T, H, W = x.shape
+    Cout, _, kt, kh, kw = w.shape
+    x = x.astype(F32)
+    if kt > 1:
+        x = np.concatenate([np.repeat(x[:, :, :1], kt - 1, axis=2), x], axis=2)
+    xp = np.pad(x, ((0, 0), (0, 0), (0, 0), (pad_hw, pad_hw), (pad_hw, pad_hw)))
+    Ho, Wo = H + 2 * pad_hw - kh + 1, W + 2 * pad_hw - kw + 1
+    out = np.zeros((B, Cout, T * Ho * Wo), F32)
+    for a in range(kt):
+        for i in range(kh):
+            for j in range(kw):
+                patch = np.ascontiguousarray(xp[:, :, a:a + T, i:i + Ho, j:j + Wo]).reshape(B, Cin, -1)
+                out += np.einsum("oc,bcn->bon", w[:, :, a, i, j].astype(F32), patch, optimize=True)
+    out = out.reshape(B, Cout, T, Ho, Wo)
+    if b is not None:
+        out += b.reshape(1, -1, 1, 1, 1)
+    return out
+
+
+def nearest_up2(x):
+    return np.repeat(np.repeat(x, 2, axis=-2), 2, axis=-1)                               # vq_model.py:375
+
+
+# ----------------------------------------------------------------------------
+# VQ-16 image tokenizer: decode + argmin  (tokenizer/tokenizer_image/vq_model.py)
+# ----------------------------------------------------------------------------
+def l2norm_rows(e, eps=1e-12):
+    n = np.sqrt(np.sum(e.astype(F32) ** 2, axis=-1, keepdims=True, dtype=F32))
+    return (e / np.maximum(n, F32(eps))).astype(F32)                                     # F.normalize
+
+
+class VQOracle:
+    def __init__(self, sd, ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, l2_norm=True):
+        self.sd = {k: np.asarray(v, F32) for k, v in sd.items()}
+        self.ch, self.ch_mult, self.nrb, self.l2 = ch, tuple(ch_mult), num_res_blocks, l2_norm
+
+    def get_codebook_entry(self, idx, shape):
+        E = self.sd["quantize.embedding.weight"]                                         # vq_model.py:261-276 (Q11)
+        if self.l2:
+            E = l2norm_rows(E)
+        z = E[np.asarray(idx).reshape(-1)]
+        return z.reshape(shape[0], shape[2], shape[3], shape[1]).transpose(0, 3, 1, 2).copy()
+
+    def argmin(self, z):
+        """VectorQuantizer.forward indices (vq_model.py:215-233). z [B,C,H,W] -> [B*H*W]."""
+        E = self.sd["quantize.embedding.weight"]
+        zf = z.transpose(0, 2, 3, 1).reshape(-1, E.shape[1]).astype(F32)
+        if self.l2:
+            zf = l2norm_rows(zf)
+            E = l2norm_rows(E)
+        d = np.sum(zf ** 2, axis=1, keepdims=True) + np.sum(E ** 2, axis=1) - F32(2) * (zf @ E.T)
+        return np.argmin(d, axis=1).astype(np.int64), d
+
+    def _res(self, p, x):
+        sd = self.sd                                                                     # vq_model.py:299-314
+        h = swish(group_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))
+        h = conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], 1)
+        h = swish(group_norm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
+        h = conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], 1)
+        if (p + ".nin_shortcut.weight") in sd:
+            x = conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"], 0)
+        return x + h
+
+    def _attn(self, p, x):
+        sd = self.sd                                                                     # vq_model.py:327-351
+        B, C, H, W = x.shape
+        h = group_norm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"])
+        q = conv2d(h, sd[p + ".q.weight"], sd[p + ".q.bias"], 0).reshape(B, C, H * W)
+        k = conv2d(h, sd[p + ".k.weight"], sd[p + ".k.bias"], 0).reshape(B, C, H * W)
+        v = conv2d(h, sd[p + ".v.weight"], sd[p + ".v.bias"], 0).reshape(B, C, H * W)
+        w_ = np.einsum("bci,bcj->bij", q, k) * F32(int(C) ** (-0.5))
+        w_ = softmax_lastdim(w_)
+        o = np.einsum("bci,bji->bcj", v, w_).reshape(B, C, H, W)
+        o = conv2d(o, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"], 0)
+        return x + o
+
+    def decode(self, quant):
+        sd = self.sd                                                                     # vq_model.py:47-50,173-194
+        h = conv2d(quant, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], 0)
+        h = conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], 1)
+        h = self._res("decoder.mid.0", h)
+        h = self._attn("decoder.mid.1", h)
+        h = self._res("decoder.mid.2", h)
+        nres = len(self.ch_mult)
+        for li in range(nres):
+            for j in range(self.nrb + 1):
+                h = self._res(f"decoder.conv_blocks.{li}.res.{j}", h)
+                if li == 0:
+                    h = self._attn(f"decoder.conv_blocks.{li}.attn.{j}", h)
+            if li != nres - 1:
+                h = nearest_up2(h)
+                p = f"decoder.conv_blocks.{li}.upsample.conv"
+                h = conv2d(h, sd[p + ".weight"], sd[p + ".bias"], 1)
+        h = swish(group_norm(h, sd["decoder.norm_out.weight"], sd["decoder.norm_out.bias"]))
+        return conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], 1)
+
+    def decode_code(self, code, shape):
+        return self.decode(self.get_codebook_entry(code, shape))                         # vq_model.py:52-55
+
+
+# ----------------------------------------------------------------------------
+# video codebook nearest neighbour
+# (tokenizer/tokenizer_video/vqvae.py:161-170 == CausalVideoVAE/.../modules/quant.py:42-54)
+# ----------------------------------------------------------------------------
+def video_codebook_argmin(z, E):
+    """z [B,C,T,H,W], E [n_codes,C] -> indices [B,T,H,W]; d = |x|^2 - 2xE^T + |E|^2."""
+    B, C = z.shape[:2]
+    flat = np.moveaxis(z, 1, -1).reshape(-1, C).astype(F32)
+    d = (flat ** 2).sum(axis=1, keepdims=True) - F32(2) * (flat @ E.T.astype(F32)) + (E.T.astype(F32) ** 2).sum(axis=0, keepdims=True)
+    return np.argmin(d, axis=1).reshape((B,) + z.shape[2:]).astype(np.int64), d
+
+
+# ----------------------------------------------------------------------------
+# CausalVideoVAE decoder  (CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py:151-262,394-404)
+# ----------------------------------------------------------------------------
+def time_upsample2x(x):
+    """TimeUpsample2x (updownsample.py:189-194): keep frame 0, trilinear x2 (align_corners=False)
+    on the rest: T -> 2T-1 (Q13)."""
+    if x.shape[2] <= 1:
+        return x
+    first, rest = x[:, :, :1], x[:, :, 1:]
+    Tn = rest.shape[2]
+    outs = []
+    for j in range(2 * Tn):
+        src = max((j + 0.5) / 2.0 - 0.5, 0.0)
+        i0 = int(math.floor(src))
+        i1 = min(i0 + 1, Tn - 1)
+        lam = F32(src - i0)
+        outs.append((F32(1) - lam) * rest[:, :, i0] + lam * rest[:, :, i1])
+    return np.concatenate([first, np.stack(outs, axis=2).astype(F32)], axis=2)
+
+
+class VAEOracle:
+    def __init__(self, sd, hidden_size=128, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2,
+                 spatial_upsample=(False, True, True, True), temporal_upsample=(False, False, True, True)):
+        self.sd = {k: np.asarray(v, F32) for k, v in sd.items()}
+        self.hs, self.mult, self.nrb = hidden_size, tuple(hidden_size_mult), num_res_blocks
+        self.sup, self.tup = tuple(spatial_upsample), tuple(temporal_upsample)
+
+    def _cc(self, p, x, pad):
+        return causal_conv3d(x, self.sd[p + ".conv.weight"], self.sd[p + ".conv.bias"], pad)
+
+    def _res(self, p, x):
+        sd = self.sd                                                                     # resnet_block.py:158-172
+        h = swish(group_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]))
+        h = self._cc(p + ".conv1", h, 1)
+        h = swish(group_norm(h, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]))
+        h = self._cc(p + ".conv2", h, 1)
+        if (p + ".nin_shortcut.conv.weight") in sd:
+            x = self._cc(p + ".nin_shortcut", x, 0)
+        return x + h
+
+    def _attn(self, p, x):
+        sd = self.sd                                                                     # attention.py:52-76
+        b, c, t, hh, ww = x.shape
+        h = group_norm(x, sd[p + ".norm.weight"], sd[p + ".norm.bias"])
+        q = self._cc(p + ".q", h, 0)
+        k = self._cc(p + ".k", h, 0)
+        v = self._cc(p + ".v", h, 0)
+        # Q12: [b,c,t,h,w] reinterpreted as [b*t, c, h*w] WITHOUT moving t ahead of c
+        q = q.reshape(b * t, c, hh * ww)
+        k = k.reshape(b * t, c, hh * ww)
+        v = v.reshape(b * t, c, hh * ww)
+        w_ = np.einsum("bci,bcj->bij", q, k) * F32(int(c) ** (-0.5))
+        w_ = softmax_lastdim(w_)
+        o = np.einsum("bci,bji->bcj", v, w_).reshape(b, c, t, hh, ww)
+        o = self._cc(p + ".proj_out", o, 0)
+        return x + o
+
+    def decode(self, z):
+        sd = self.sd
+        z = self._cc("post_quant_conv", z, 0)                                            # modeling_causalvae.py:401-402
+        h = self._cc("decoder.conv_in", z, 1)
+        h = self._res("decoder.mid.block_1", h)
+        h = self._attn("decoder.mid.attn_1", h)
+        h = self._res("decoder.mid.block_2", h)
+        for i_level in reversed(range(len(self.mult))):                                  # :249-257
+            for j in range(self.nrb + 1):
+                h = self._res(f"decoder.up.{i_level}.block.{j}", h)
+            if self.sup[i_level]:
+                h = nearest_up2(h)                                                       # updownsample.py:146-153
+                h = self._cc(f"decoder.up.{i_level}.upsample.conv", h, 1)
+            if self.tup[i_level]:
+                h = time_upsample2x(h)
+        h = swish(group_norm(h, sd["decoder.norm_out.weight"], sd["decoder.norm_out.bias"]))
+        return self._cc("decoder.conv_out", h, 1)

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (/root/reference) on CPU.
+
+    python tests/golden/make_goldens.py [--only gpt,sampler,vq,vae,t2v,gptb]
+
+Only runs in the build container (needs /root/reference); outputs are small .npz
+fixtures committed under tests/golden/.  The inputs/weights are regenerated from
+seeds (oracle/cases.py, oracle/detweights.py), so fixtures hold expected outputs only.
+torch 2.10.0 CPU kernels, default matmul precision (true fp32).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import cases, detweights, ref_harness  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def build_ref_gpt(gptmod, cfg, dtype):
+    args = gptmod.ModelArgs(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"],
+                            vocab_size=cfg["vocab_size"], block_size=cfg["block_size"],
+                            cls_token_num=cfg["cls_token_num"], model_type=cfg["model_type"],
+                            num_classes=cfg["num_classes"], caption_dim=cfg["caption_dim"],
+                            **({k: cfg[k] for k in ("vae_embed_dim", "num_frames", "t_downsample_size") if k in cfg}
+                               if cfg["model_type"] == "t2v" else {}),
+                            **({"shuffle_video_tokens": False} if cfg["model_type"] == "t2v" else {}))
+    m = gptmod.Transformer(args)
+    sd = detweights.gpt_weights(cfg)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("freqs") for k in missing), missing
+    return m.to(dtype).eval()
+
+
+def ref_generate_trace(genmod, model, cond, N, emb_masks, cfg_scale, cfg_interval, **kw):
+    """generate() + capture of the combined logits fed to sample() at each step."""
+    captured = []
+    orig = genmod.sample
+
+    def spy(logits, **k):
+        captured.append(logits[:, -1, :].float().clone().numpy())
+        return orig(logits, **k)
+
+    genmod.sample = spy
+    try:
+        ids = genmod.generate(model, cond, N, emb_masks, cfg_scale=cfg_scale, cfg_interval=cfg_interval, **kw)
+    finally:
+        genmod.sample = orig
+    return ids.numpy(), np.stack(captured, 0)
+
+
+def gold_rope(out):
+    gptmod, _ = ref_harness.load_gpt()
+    gv = ref_harness.load_gpt_video()
+    for g, hd, cls in ((16, 64, 1), (24, 100, 1), (4, 64, 8), (32, 64, 120)):
+        tab = gptmod.precompute_freqs_cis_2d(g, hd, 10000, cls).numpy()
+        out[f"rope2d_g{g}_hd{hd}_c{cls}_sum"] = np.array([tab.astype(np.float64).sum(), np.abs(tab).astype(np.float64).sum()])
+        out[f"rope2d_g{g}_hd{hd}_c{cls}_rows"] = tab[[0, cls, cls + 1, cls + g, cls + g * g - 1]]
+    tab = gv.precompute_freqs_cis_3d_video(4, 3, 64, 10000, 8).numpy()
+    out["rope3d_g4_t3_hd64_c8"] = tab
+
+
+def gold_gpt(out):
+    gptmod, genmod = ref_harness.load_gpt()
+    for tag, cfg in (("c2i", cases.TINY_C2I), ("t2i", cases.TINY_T2I), ("hd100", cases.TINY_HD100)):
+        N = cfg["block_size"]
+        for dt_name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            m = build_ref_gpt(gptmod, cfg, dtype)
+            B = 3
+            if cfg["model_type"] == "c2i":
+                cond, masks = t(cases.class_ids(B, cfg["num_classes"])), None
+            else:
+                c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[120, 3, 57])
+                cond, masks = t(c).to(dtype), t(mk)
+            # greedy, no cfg
+            ids, lg = ref_generate_trace(genmod, m, cond, N, masks, 1.0, -1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+            out[f"{tag}_{dt_name}_greedy_ids"] = ids
+            out[f"{tag}_{dt_name}_greedy_logits"] = lg.astype(np.float32)
+            # greedy + cfg + cfg_interval
+            ids, lg = ref_generate_trace(genmod, m, cond, N, masks, 2.5, 6, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+            out[f"{tag}_{dt_name}_cfg_ids"] = ids
+            out[f"{tag}_{dt_name}_cfg_logits"] = lg.astype(np.float32)
+            # stochastic: shared exponential noise through a patched torch.multinomial
+            noise = cases.exp_noise((N, B, cfg["vocab_size"]), seed=7)
+            step = [0]
+            orig_mn = torch.multinomial
+
+            def mn(probs, num_samples=1, **k):
+                q = t(noise[step[0]])
+                step[0] += 1
+                return torch.argmax(probs / q, dim=-1, keepdim=True)
+
+            torch.multinomial = mn
+            try:
+                ids, lg = ref_generate_trace(genmod, m, cond, N, masks, 3.0, -1, temperature=0.9, top_k=50, top_p=0.95, sample_logits=True)
+            finally:
+                torch.multinomial = orig_mn
+            out[f"{tag}_{dt_name}_sample_ids"] = ids
+            out[f"{tag}_{dt_name}_sample_logits0"] = lg[0].astype(np.float32)
+
+
+def gold_sampler(out):
+    _, genmod = ref_harness.load_gpt()
+    logits = cases.sampler_logits()
+    q = cases.exp_noise(logits.shape, seed=13)
+    grid = [(0, 1.0, 1.0), (1000, 1.0, 1.0), (2000, 1.0, 0.7), (0, 0.9, 1.0), (100, 0.8, 1.3), (1, 1.0, 1.0), (16384, 0.5, 1.0), (300, 0.3, 0.5)]
+    out["sampler_grid"] = np.array(grid, np.float64)
+    for gi, (k, p, temp) in enumerate(grid):
+        lg = t(logits.copy())[:, None, :]
+        idx, probs = genmod.sample(lg, temperature=temp, top_k=int(k), top_p=p, sample_logits=False)
+        probs = probs.numpy()
+        out[f"sampler_{gi}_greedy"] = idx.numpy().reshape(-1)
+        out[f"sampler_{gi}_nnz"] = (probs > 0).sum(-1)
+        out[f"sampler_{gi}_pmax"] = probs.max(-1)
+        out[f"sampler_{gi}_psum_top"] = np.sort(probs, -1)[:, -16:].astype(np.float64).sum(-1)
+        out[f"sampler_{gi}_noise_idx"] = np.argmax(probs / q, -1)
+        # torch.multinomial itself under a seeded CPU generator == argmax(p / exponential_)
+        g = torch.Generator().manual_seed(1234)
+        e = torch.empty(probs.shape).exponential_(1, generator=g)
+        g2 = torch.Generator().manual_seed(1234)
+        mn = torch.multinomial(t(probs), 1, generator=g2).reshape(-1).numpy()
+        assert (np.argmax(probs / e.numpy(), -1) == mn).all()
+    # engineered ties for top-k (ties kept, Q5)
+    tie = np.zeros((1, 64), np.float32)
+    tie[0, :10] = 5.0
+    tie[0, 10:20] = 4.0
+    f = genmod.top_k_top_p_filtering(t(tie.copy()), top_k=12, top_p=1.0).numpy()
+    out["sampler_tie_kept"] = np.isfinite(f).sum(-1)
+
+
+def build_ref_vq(vqmod, sd):
+    m = vqmod.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
+    full = m.state_dict()
+    for k, v in sd.items():
+        assert k in full and tuple(full[k].shape) == v.shape, k
+        full[k] = t(v)
+    m.load_state_dict(full)
+    return m.eval()
+
+
+def gold_vq(out):
+    vqmod = ref_harness.load_vq()
+    sd = detweights.vq_weights()
+    m = build_ref_vq(vqmod, sd)
+    g = 4
+    code = cases.rng(21).integers(0, 16384, size=(2, g * g)).astype(np.int64)
+    q = m.quantize.get_codebook_entry(t(code), [2, 8, g, g], True)
+    out["vq_entry"] = q.numpy()
+    img = m.decode_code(t(code), [2, 8, g, g])
+    out["vq_decode_g4"] = img.numpy()
+    # unit I/O of the post_quant+conv_in+mid stage and one upsample level, for localisation
+    h = m.post_quant_conv(q)
+    h = m.decoder.conv_in(h)
+    out["vq_conv_in"] = h.numpy()
+    for blk in m.decoder.mid:
+        h = blk(h)
+    out["vq_mid"] = h.numpy()
+    # argmin incl. engineered ties (two identical codebook rows -> first index wins)
+    z = cases.rng(22).standard_normal((2, 8, 6, 6), dtype=np.float32)
+    _, _, (_, _, idx) = m.quantize(t(z))
+    out["vq_argmin"] = idx.numpy()
+    m2 = build_ref_vq(vqmod, sd)
+    w = m2.quantize.embedding.weight.data
+    w[777] = w[5]
+    zz = torch.nn.functional.normalize(w[[5, 5, 9]], dim=-1).reshape(1, 3, 1, 8).permute(0, 3, 1, 2).contiguous()
+    _, _, (_, _, idx2) = m2.quantize(zz)
+    out["vq_argmin_tie"] = idx2.numpy()
+
+
+def gold_vae(out):
+    Decoder, mods = ref_harness.load_vae_decoder_cls()
+    cfg = cases.TINY_VAE
+    sd = detweights.vae_weights(cfg)
+    dec = Decoder(z_channels=cfg["z_channels"], hidden_size=cfg["hidden_size"], hidden_size_mult=cfg["hidden_size_mult"],
+                  attn_resolutions=[], conv_in="CausalConv3d", conv_out="CausalConv3d", attention="AttnBlock3D",
+                  resnet_blocks=("ResnetBlock3D",) * 4, spatial_upsample=("", "SpatialUpsample2x", "SpatialUpsample2x", "SpatialUpsample2x"),
+                  temporal_upsample=("", "", "TimeUpsample2x", "TimeUpsample2x"), mid_resnet="ResnetBlock3D",
+                  dropout=0.0, resolution=256, num_res_blocks=cfg["num_res_blocks"]).eval()
+    dsd = {k[len("decoder."):]: t(v) for k, v in sd.items() if k.startswith("decoder.")}
+    dec.load_state_dict(dsd)
+    pq = mods.CausalConv3d(cfg["embed_dim"], cfg["z_channels"], 1)
+    pq.load_state_dict({"conv.weight": t(sd["post_quant_conv.conv.weight"]), "conv.bias": t(sd["post_quant_conv.conv.bias"])})
+    z = cases.rng(31).standard_normal((1, cfg["embed_dim"], 3, 4, 4), dtype=np.float32)
+    y = dec(pq(t(z)))                                   # CausalVAEModel.decode, modeling_causalvae.py:401-403
+    out["vae_decode"] = y.numpy()
+    z1 = cases.rng(32).standard_normal((2, cfg["embed_dim"], 1, 4, 4), dtype=np.float32)
+    out["vae_decode_1f"] = dec(pq(t(z1))).numpy()
+    # unit I/O: AttnBlock3D at t=3 (Q12), TimeUpsample2x, CausalConv3d k3
+    x = cases.rng(33).standard_normal((1, 128, 3, 4, 4), dtype=np.float32)
+    out["vae_attn_t3"] = dec.mid.attn_1(t(x)).numpy()
+    x2 = cases.rng(34).standard_normal((1, 4, 5, 2, 2), dtype=np.float32)
+    out["vae_timeup"] = mods.TimeUpsample2x(4, 4)(t(x2)).numpy()
+    out["vae_conv_in"] = dec.conv_in(pq(t(z))).numpy()
+
+
+def gold_t2v(out):
+    gv = ref_harness.load_gpt_video()
+    cfg = cases.TINY_T2V
+    vae_t = (cfg["num_frames"] - 1) // cfg["t_downsample_size"] + 1
+    N = vae_t * cfg["block_size"]
+    for dt_name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = build_ref_gpt(gv, cfg, dtype)
+        B = 2
+        c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 4])
+        # batched prefill + decode with the reference Transformer (cfg=1), mask fix-up as generate.py:156-165
+        T = cfg["cls_token_num"]
+        m.setup_caches(B, T + N, dtype)
+        m.causal_mask[:, :, :T] = m.causal_mask[:, :, :T] * t(mk).bool().unsqueeze(1)
+        eye = torch.eye(m.causal_mask.size(1), m.causal_mask.size(2))
+        m.causal_mask[:] = (m.causal_mask * (1 - eye) + eye).bool()
+        outs = []
+        h, _ = m(cond_embed=t(c).to(dtype), video_latent=None, input_pos=torch.arange(T))
+        e = h[:, -1:, :]
+        outs.append(e.float().numpy())
+        for i in range(N - 1):
+            h, _ = m(cond_embed=None, video_latent=e, input_pos=torch.tensor([T + i]))
+            e = h[:, -1:, :]
+            outs.append(e.float().numpy())
+        out[f"t2v_{dt_name}_latents"] = np.concatenate(outs, 1)
+
+
+def gold_gptb(out):
+    """BASELINE config 1: GPT-B c2i 16x16 greedy fp32, B=1: ids + top1-top2 margins."""
+    gptmod, genmod = ref_harness.load_gpt()
+    m = build_ref_gpt(gptmod, cases.GPT_B, torch.float32)
+    cond = t(cases.class_ids(1, 1000, seed=0))
+    ids, lg = ref_generate_trace(genmod, m, cond, 256, None, 1.0, -1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=False)
+    srt = np.sort(lg[:, 0, :], -1)
+    out["gptb_ids"] = ids
+    out["gptb_margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+    out["gptb_logits_step0"] = lg[0, 0].astype(np.float32)
+    out["gptb_top1"] = srt[:, -1].astype(np.float32)
+
+
+PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=",".join(PARTS))
+    a = ap.parse_args()
+    for name in a.only.split(","):
+        out = {}
+        PARTS[name](out)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, os.path.getsize(path) // 1024, "KB", flush=True)
