@@ -1,0 +1,172 @@
+/* libvlg - MI355X (gfx950) native KV-cached visual-token sampling + VQ / CausalVideoVAE decode.
+ *
+ * C-ABI drop-in boundary for ONE hot path of BinZhu-ece/Video-LlamaGen.  The reference has no
+ * FFI for this path (it sits behind Python callables); each entry point below names
+ * the reference callable it replaces (paths relative to the reference root).  No torch types cross
+ * this boundary: plain pointers, sizes, opaque handles, int status codes.
+ *
+ * Conventions
+ *  - every function returns VLG_OK (0) or a negative vlg_status; vlg_last_error() gives the text.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued
+ *    asynchronously on it; the caller synchronises.
+ *  - pointers named d_* are DEVICE pointers owned by the caller; weights / KV caches / workspaces are
+ *    owned by the handle.  One handle is used by one host thread at a time (the reference's model
+ *    object owns its caches and is not re-entrant either, gpt.py:318-332).
+ *  - dtype codes: VLG_F32 = 0, VLG_BF16 = 1.
+ */
+#ifndef VLG_H
+#define VLG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VLG_OK = 0,
+  VLG_ERR_BAD_ARG = -1,      /* NULL pointer / negative size / unknown name          */
+  VLG_ERR_BAD_SHAPE = -2,    /* tensor shape does not match the configuration        */
+  VLG_ERR_UNSUPPORTED = -3,  /* head_dim / dtype / model_type not supported          */
+  VLG_ERR_OOM = -4,          /* hipMalloc failed                                     */
+  VLG_ERR_HIP = -5,          /* any other HIP runtime error                          */
+  VLG_ERR_STATE = -6         /* weights missing / call order violated                */
+} vlg_status;
+
+enum { VLG_F32 = 0, VLG_BF16 = 1 };
+enum { VLG_C2I = 0, VLG_T2I = 1, VLG_T2V = 2 };
+enum { VLG_HEAD_LOGITS = 0, VLG_HEAD_ADAPTER2 = 1, VLG_HEAD_HIDDEN = 2 };
+
+const char* vlg_last_error(void);
+/* 3 ints: major, minor, gfx arch (950) */
+void vlg_version(int* out3);
+
+/* ------------------------------------------------------------------------------------------
+ * GPT (Llama-style decoder)     replaces autoregressive/models/gpt.py:262-371 `Transformer`,
+ *                               gpt_video.py:270-431 (t2v, adapter2 head)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlg_gpt vlg_gpt_t;
+
+typedef struct {
+  int32_t dim, n_layer, n_head;      /* ModelArgs, gpt.py:23-50                              */
+  int32_t vocab_size, block_size, cls_token_num;
+  int32_t model_type;                /* VLG_C2I | VLG_T2I | VLG_T2V                          */
+  int32_t num_classes, caption_dim;
+  int32_t vae_embed_dim, num_frames, t_downsample_size; /* gpt_video.py:58-60                */
+  int32_t head;                      /* VLG_HEAD_*                                           */
+  int32_t dtype;                     /* compute/storage dtype of weights, activations, KV    */
+  int32_t multiple_of;               /* SwiGLU hidden rounding, gpt.py:29,154-159            */
+  float norm_eps, rope_base;
+} vlg_gpt_config;
+
+int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out);
+int vlg_gpt_destroy(vlg_gpt_t* h);
+/* State-dict entry by its reference name ("layers.3.attention.wqkv.weight", ...).
+ * `data` is fp32 or bf16 (src_dtype), host (src_on_device=0) or device memory; it is converted to the
+ * handle dtype and copied.  Unknown names ("freqs_cis", training-only tensors) return VLG_OK with
+ * *consumed = 0 (strict=False semantics of sample_t2i.py:71).                                   */
+int vlg_gpt_load_tensor(vlg_gpt_t* h, const char* name, const void* data, const int64_t* shape,
+                        int32_t ndim, int32_t src_dtype, int32_t src_on_device, int32_t* consumed);
+
+typedef struct {
+  float cfg_scale;       /* generate.py:128; CFG doubles the batch when > 1                    */
+  int32_t cfg_interval;  /* generate.py:113-114 (Q7)                                           */
+  float temperature;     /* generate.py:58                                                     */
+  int32_t top_k;         /* generate.py:32-36; 0 = off                                         */
+  float top_p;           /* generate.py:38-53; 1.0 = off                                       */
+  int32_t sample_logits; /* 1 = multinomial, 0 = greedy argmax (generate.py:62-65)             */
+  uint64_t seed;         /* Philox seed for the on-device Exp(1) noise when d_noise == NULL    */
+} vlg_sampling_params;
+
+/* replaces generate() autoregressive/models/generate.py:127-180 (c2i/t2i) and the skeleton of
+ * generate_video_diff.py:185-228 with the gpt_video.py:431 head (t2v).
+ *   d_cond      c2i: int64 [B] class ids; t2i/t2v: fp32 [B, cls_token_num, caption_dim] (already * mask)
+ *   d_emb_mask  fp32 [B, cls_token_num] (1 = valid, left-padded) or NULL
+ *   d_noise     fp32 [N, B, vocab] Exp(1) draws consumed as argmax(p / q) or NULL (-> Philox(seed))
+ *   d_out_ids   int32 [B, N]            (logits head)
+ *   d_out_lat   fp32  [B, N, vae_embed_dim]  (adapter2 / hidden head)
+ *   d_trace     optional fp32 [N, B, vocab|C]: the CFG-combined head output fed to the sampler */
+int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, int32_t B, int32_t N,
+                     const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids,
+                     float* d_out_lat, float* d_trace, void* stream);
+
+/* bytes the last generate() call moved algorithmically (weights + KV read/write + logits), for roofline */
+int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* kv_bytes, double* other_bytes);
+/* use HIP graph replay for the decode loop (default 1) */
+int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
+
+/* ------------------------------------------------------------------------------------------
+ * Unit entry points (parity tests call the very kernels the handle uses)
+ * ------------------------------------------------------------------------------------------ */
+/* RMSNorm gpt.py:137-148.  x,out [rows, dim] in `dtype`, w [dim] in `dtype` */
+int vlg_rmsnorm(const void* d_x, const void* d_w, void* d_out, int32_t rows, int32_t dim, float eps,
+                int32_t dtype, void* stream);
+/* bias-free Linear gpt.py:199-200,161-163: out[M,N] = x[M,K] @ w[N,K]^T (fp32 accumulate, output `dtype`) */
+int vlg_linear(const void* d_x, const void* d_w, void* d_out, int32_t M, int32_t N, int32_t K,
+               int32_t dtype, void* stream);
+/* RoPE table gpt.py:407-420 / gpt_video.py:532-552 -> host fp32 [cls + vae_t*grid^2, hd/2, 2] */
+int vlg_rope_table(int32_t grid, int32_t vae_t, int32_t head_dim, float base, int32_t cls_token_num,
+                   float* host_out);
+/* sampler generate.py:16-66 + CFG combine :81-82.  d_logits fp32 [Bp, V] (Bp = 2B if cfg_on),
+ * d_noise fp32 [B,V] or NULL, outputs int32 [B] and optional probs fp32 [B,V]                 */
+int vlg_sample(const float* d_logits, int32_t B, int32_t V, int32_t cfg_on, const vlg_sampling_params* sp,
+               const float* d_noise, uint64_t step, int32_t* d_out_idx, float* d_out_probs, void* stream);
+/* single-query attention over a KV cache, gpt.py:226-237 (decode step).
+ * q [Bp,H,hd], k/v cache [Bp,H,S,hd] all `dtype`; attends keys 0..pos for every row;
+ * d_mask fp32 [Bmask, Tc] or NULL (text padding, generate.py:156-165), out [Bp, H*hd]          */
+int vlg_attn_decode(const void* d_q, const void* d_k, const void* d_v, void* d_out, int32_t Bp, int32_t H,
+                    int32_t S, int32_t hd, int32_t pos, const float* d_mask, int32_t Bmask, int32_t Tc,
+                    int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VQ-16 / VQ-8 image tokenizer   replaces tokenizer/tokenizer_image/vq_model.py
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlg_vq vlg_vq_t;
+typedef struct {
+  int32_t codebook_size, codebook_embed_dim, z_channels, ch; /* vq_model.py:13-24,129            */
+  int32_t n_mult;
+  int32_t ch_mult[8];                                        /* decoder_ch_mult                  */
+  int32_t num_res_blocks;
+  int32_t l2_norm;                                           /* codebook_l2_norm                 */
+  int32_t dtype;                                             /* activation/weight compute dtype  */
+} vlg_vq_config;
+int vlg_vq_create(const vlg_vq_config* cfg, vlg_vq_t** out);
+int vlg_vq_destroy(vlg_vq_t* h);
+int vlg_vq_load_tensor(vlg_vq_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                       int32_t src_dtype, int32_t src_on_device, int32_t* consumed);
+/* VQModel.decode_code vq_model.py:52-55: d_codes int32 [B, gh*gw] -> d_out fp32 [B,3,16gh,16gw] (NCHW) */
+int vlg_vq_decode_code(vlg_vq_t* h, const int32_t* d_codes, int32_t B, int32_t gh, int32_t gw, float* d_out,
+                       void* stream);
+/* VectorQuantizer.forward indices vq_model.py:215-233: d_z fp32 [B,C,H,W] -> int32 [B*H*W]            */
+int vlg_vq_argmin(vlg_vq_t* h, const float* d_z, int32_t B, int32_t Hh, int32_t Ww, int32_t* d_idx, void* stream);
+/* Codebook.forward argmin, tokenizer_video/vqvae.py:161-170 (== CausalVideoVAE quant.py:42-54):
+ * d_z fp32 [n, dim] rows, d_codebook fp32 [n_codes, dim] -> int32 [n] (no normalisation)              */
+int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim,
+                        int32_t* d_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CausalVideoVAE decoder   replaces CausalVAEModel.decode modeling_causalvae.py:394-404
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlg_vae vlg_vae_t;
+typedef struct {
+  int32_t hidden_size, z_channels, embed_dim, num_res_blocks; /* modeling_causalvae.py:268-320   */
+  int32_t n_mult;
+  int32_t hidden_size_mult[8];
+  int32_t spatial_upsample[8];   /* per level (index = i_level) 0/1                              */
+  int32_t temporal_upsample[8];
+  int32_t dtype;
+} vlg_vae_config;
+int vlg_vae_create(const vlg_vae_config* cfg, vlg_vae_t** out);
+int vlg_vae_destroy(vlg_vae_t* h);
+int vlg_vae_load_tensor(vlg_vae_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                        int32_t src_dtype, int32_t src_on_device, int32_t* consumed);
+/* d_z fp32 [B, embed_dim, t, h, w] (NCTHW) -> d_out fp32 [B, 3, T, 8h, 8w], T = 4(t-1)+1 for the
+ * default config.  Tiling never triggers at the benchmark shape.                        */
+int vlg_vae_decode(vlg_vae_t* h, const float* d_z, int32_t B, int32_t t, int32_t hh, int32_t ww, float* d_out,
+                   void* stream);
+int vlg_vae_out_shape(vlg_vae_t* h, int32_t t, int32_t hh, int32_t ww, int32_t* T, int32_t* H, int32_t* W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLG_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of libvlg.so (include/vlg.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvlg.so")
+
+VLG_F32, VLG_BF16 = 0, 1
+VLG_C2I, VLG_T2I, VLG_T2V = 0, 1, 2
+VLG_HEAD_LOGITS, VLG_HEAD_ADAPTER2, VLG_HEAD_HIDDEN = 0, 1, 2
+
+STATUS = {0: "VLG_OK", -1: "VLG_ERR_BAD_ARG", -2: "VLG_ERR_BAD_SHAPE", -3: "VLG_ERR_UNSUPPORTED",
+          -4: "VLG_ERR_OOM", -5: "VLG_ERR_HIP", -6: "VLG_ERR_STATE"}
+
+
+class VlgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, code), msg))
+        self.code = code
+
+
+class GptConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "num_classes",
+        "caption_dim", "vae_embed_dim", "num_frames", "t_downsample_size", "head", "dtype", "multiple_of")] + [
+        ("norm_eps", C.c_float), ("rope_base", C.c_float)]
+
+
+class SamplingParams(C.Structure):
+    _fields_ = [("cfg_scale", C.c_float), ("cfg_interval", C.c_int32), ("temperature", C.c_float),
+                ("top_k", C.c_int32), ("top_p", C.c_float), ("sample_logits", C.c_int32), ("seed", C.c_uint64)]
+
+
+class VqConfig(C.Structure):
+    _fields_ = [("codebook_size", C.c_int32), ("codebook_embed_dim", C.c_int32), ("z_channels", C.c_int32),
+                ("ch", C.c_int32), ("n_mult", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
+                ("l2_norm", C.c_int32), ("dtype", C.c_int32)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("z_channels", C.c_int32), ("embed_dim", C.c_int32),
+                ("num_res_blocks", C.c_int32), ("n_mult", C.c_int32), ("hidden_size_mult", C.c_int32 * 8),
+                ("spatial_upsample", C.c_int32 * 8), ("temporal_upsample", C.c_int32 * 8), ("dtype", C.c_int32)]
+
+
+# every symbol include/vlg.h declares
+SYMBOLS = [
+    "vlg_last_error", "vlg_version",
+    "vlg_gpt_create", "vlg_gpt_destroy", "vlg_gpt_load_tensor", "vlg_gpt_generate",
+    "vlg_gpt_last_algorithmic_bytes", "vlg_gpt_set_option",
+    "vlg_rmsnorm", "vlg_linear", "vlg_rope_table", "vlg_sample", "vlg_attn_decode",
+    "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",
+    "vlg_codebook_argmin",
+    "vlg_vae_create", "vlg_vae_destroy", "vlg_vae_load_tensor", "vlg_vae_decode", "vlg_vae_out_shape",
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it was never built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libvlg.so is missing at %s - build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.vlg_last_error.restype = C.c_char_p
+        for s in SYMBOLS:
+            getattr(_lib, s)  # AttributeError if the header and the library ever diverge
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise VlgError(code, lib().vlg_last_error().decode(errors="replace"))
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def torch_dtype_code(dt):
+    import torch
+    if dt == torch.float32:
+        return VLG_F32
+    if dt == torch.bfloat16:
+        return VLG_BF16
+    raise VlgError(-3, "unsupported dtype %s (float32 and bfloat16 only)" % dt)
+
+
+def load_tensor(fn, handle, name, t):
+    """Uploads one state-dict tensor through a *_load_tensor entry point; returns True if it was consumed."""
+    import torch
+    t = t.detach()
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    t = t.contiguous()
+    shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+    consumed = C.c_int32(0)
+    check(fn(handle, name.encode(), ptr(t), shape, C.c_int32(t.dim()), C.c_int32(torch_dtype_code(t.dtype)),
+             C.c_int32(1 if t.is_cuda else 0), C.byref(consumed)))
+    return bool(consumed.value)

@@ -1,0 +1,518 @@
+// vlg_gpt handle: weights, KV cache, workspaces and the prefill + decode loop (HIP-graph replayed).
+//
+// Replaces: Transformer (autoregressive/models/gpt.py:262-371; t2v: gpt_video.py:270-431) and generate()
+// (autoregressive/models/generate.py:127-180; t2v skeleton generate_video_diff.py:185-228).
+//
+// HBM layout (all in the handle dtype T unless noted):
+//   weights        one allocation per state-dict tensor, [out, in] row-major exactly as nn.Linear stores them;
+//                  w1 and w3 share one [2F, D] tensor so SwiGLU's two projections are one weight stream.
+//   KV cache       [L][Bp][H][S][hd] for K and for V; S = roundup8(T + N) (gpt.py:322).  Only rows 0..p are ever read.
+//   freqs          fp32 [cls + vae_t*g*g, hd/2, 2]; the first cls rows are zero (Q1).
+//   slabs          fp32 [splits][M][N] split-K partial sums, consumed by the next kernel.
+//   StepState      {pos, step} in device memory, bumped by a 1-thread kernel so the decode step graph is replayable.
+#include <cmath>
+#include <memory>
+
+#include "gpt_kernels.h"
+
+using namespace vlg;
+
+struct vlg_gpt {
+  vlg_gpt_config cfg;
+  int D, H, hd, L, F, V, Tc, C, cd, vae_t, grid, npos;
+  int dtype;
+  size_t esz;
+  struct Spec {
+    std::vector<int64_t> shape;  // expected source shape
+    std::string target;          // tensor in `w`
+    int64_t row_off;             // row offset inside target (w1/w3 merge)
+  };
+  std::map<std::string, Spec> specs;
+  std::map<std::string, Tensor> w;
+  DevBuf freqs;
+
+  // per-generate state
+  int Bp_cap = 0, S_cap = 0, M_cap = 0;
+  DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat, maskbuf;
+  hipStream_t s_int = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool use_graph = true;
+  double bytes_w = 0, bytes_kv = 0, bytes_other = 0;
+
+  ~vlg_gpt() {
+    if (s_int) (void)hipStreamDestroy(s_int);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+  }
+  const void* W(const std::string& n) const { return w.at(n).buf.p; }
+};
+
+static int ffn_hidden(int dim, int multiple_of) {
+  int hidden = 4 * dim;
+  hidden = (int)(2 * (long long)hidden / 3);
+  return hidden % multiple_of == 0 ? hidden : hidden + multiple_of - (hidden % multiple_of);
+}
+
+// RoPE table, gpt.py:407-420 / gpt_video.py:532-552 (float math as torch does on CPU)
+static void rope_table_host(int grid, int vae_t, int hd, float base, int cls, std::vector<float>& out) {
+  const int half = hd / 2;
+  const int nf = half / 2;  // arange(0, half, 2)[: half//2]
+  std::vector<float> freqs(nf);
+  for (int i = 0; i < nf; ++i) freqs[i] = 1.0f / powf(base, (float)(2 * i) / (float)half);
+  const int npos = cls + vae_t * grid * grid;
+  out.assign((size_t)npos * half * 2, 0.f);
+  for (int tt = 0; tt < vae_t; ++tt)
+    for (int r = 0; r < grid; ++r)
+      for (int c = 0; c < grid; ++c) {
+        float* row = out.data() + ((size_t)cls + ((size_t)tt * grid + r) * grid + c) * half * 2;
+        for (int i = 0; i < nf; ++i) {
+          const float fr = (float)r * freqs[i], fc = (float)c * freqs[i];
+          row[2 * i] = cosf(fr);
+          row[2 * i + 1] = sinf(fr);
+          row[2 * (nf + i)] = cosf(fc);
+          row[2 * (nf + i) + 1] = sinf(fc);
+        }
+      }
+}
+
+extern "C" int vlg_rope_table(int32_t grid, int32_t vae_t, int32_t head_dim, float base, int32_t cls, float* host_out) {
+  VLG_CHECK(host_out && grid > 0 && vae_t > 0 && head_dim > 0 && head_dim % 4 == 0 && cls >= 0, VLG_ERR_BAD_ARG,
+            "vlg_rope_table: bad argument");
+  std::vector<float> t;
+  rope_table_host(grid, vae_t, head_dim, base, cls, t);
+  memcpy(host_out, t.data(), t.size() * sizeof(float));
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out) {
+  VLG_CHECK(cfg && out, VLG_ERR_BAD_ARG, "vlg_gpt_create: null argument");
+  VLG_CHECK(cfg->dim > 0 && cfg->n_head > 0 && cfg->n_layer > 0 && cfg->dim % cfg->n_head == 0, VLG_ERR_BAD_SHAPE,
+            "vlg_gpt_create: dim %d not divisible by n_head %d", cfg->dim, cfg->n_head);
+  VLG_CHECK(cfg->dtype == VLG_F32 || cfg->dtype == VLG_BF16, VLG_ERR_UNSUPPORTED, "vlg_gpt_create: dtype %d", cfg->dtype);
+  VLG_CHECK(cfg->model_type >= VLG_C2I && cfg->model_type <= VLG_T2V, VLG_ERR_UNSUPPORTED, "please check model type");
+  const int hd = cfg->dim / cfg->n_head;
+  VLG_CHECK(hd == 32 || hd == 64 || hd == 96 || hd == 100 || hd == 128, VLG_ERR_UNSUPPORTED, "head_dim %d unsupported", hd);
+  const int grid = (int)lround(sqrt((double)cfg->block_size));
+  VLG_CHECK(grid * grid == cfg->block_size, VLG_ERR_BAD_SHAPE, "block_size %d is not a square", cfg->block_size);
+  std::unique_ptr<vlg_gpt> h(new vlg_gpt());
+  h->cfg = *cfg;
+  h->D = cfg->dim;
+  h->H = cfg->n_head;
+  h->hd = hd;
+  h->L = cfg->n_layer;
+  h->F = ffn_hidden(cfg->dim, cfg->multiple_of > 0 ? cfg->multiple_of : 256);
+  h->V = cfg->vocab_size;
+  h->Tc = cfg->cls_token_num;
+  h->C = cfg->vae_embed_dim;
+  h->cd = cfg->caption_dim;
+  h->grid = grid;
+  h->vae_t = cfg->model_type == VLG_T2V ? (cfg->num_frames - 1) / cfg->t_downsample_size + 1 : 1;
+  h->dtype = cfg->dtype;
+  h->esz = dtype_size(cfg->dtype);
+  if (cfg->model_type == VLG_C2I) VLG_CHECK(h->Tc == 1, VLG_ERR_BAD_SHAPE, "c2i needs cls_token_num == 1");
+  if (cfg->model_type == VLG_T2V)
+    VLG_CHECK(cfg->head == VLG_HEAD_ADAPTER2 || cfg->head == VLG_HEAD_HIDDEN, VLG_ERR_UNSUPPORTED, "t2v needs adapter2/hidden head");
+  else
+    VLG_CHECK(cfg->head == VLG_HEAD_LOGITS, VLG_ERR_UNSUPPORTED, "c2i/t2i need the logits head");
+
+  const int64_t D = h->D, F = h->F, V = h->V;
+  auto add = [&](const std::string& name, std::vector<int64_t> shape, const std::string& target = "", int64_t row_off = 0,
+                 std::vector<int64_t> tshape = {}) {
+    vlg_gpt::Spec s;
+    s.shape = shape;
+    s.target = target.empty() ? name : target;
+    s.row_off = row_off;
+    h->specs[name] = s;
+    Tensor& t = h->w[s.target];
+    if (t.shape.empty()) t.shape = tshape.empty() ? shape : tshape;
+  };
+  if (cfg->model_type == VLG_C2I) {
+    add("cls_embedding.embedding_table.weight", {cfg->num_classes + 1, D});
+  } else {
+    add("cls_embedding.cap_proj.fc1.weight", {D, h->cd});
+    add("cls_embedding.cap_proj.fc2.weight", {D, D});
+    add("cls_embedding.uncond_embedding", {120, h->cd});
+  }
+  if (cfg->model_type == VLG_T2V) {
+    add("vae_latent_adapter.fc1.weight", {D, h->C});
+    add("vae_latent_adapter.fc2.weight", {D, D});
+    if (cfg->head == VLG_HEAD_ADAPTER2) {
+      add("vae_latent_adapter2.fc1.weight", {D, D});
+      add("vae_latent_adapter2.fc2.weight", {h->C, D});
+    }
+  } else {
+    add("tok_embeddings.weight", {V, D});
+    add("output.weight", {V, D});
+  }
+  for (int i = 0; i < h->L; ++i) {
+    const std::string p = "layers." + std::to_string(i) + ".";
+    add(p + "attention.wqkv.weight", {3 * D, D});
+    add(p + "attention.wo.weight", {D, D});
+    add(p + "feed_forward.w1.weight", {F, D}, p + "feed_forward.w13", 0, {2 * F, D});
+    add(p + "feed_forward.w3.weight", {F, D}, p + "feed_forward.w13", F, {2 * F, D});
+    add(p + "feed_forward.w2.weight", {D, F});
+    add(p + "attention_norm.weight", {D});
+    add(p + "ffn_norm.weight", {D});
+  }
+  add("norm.weight", {D});
+  for (auto& kv : h->w) VLG_TRY(kv.second.buf.reserve((size_t)kv.second.numel() * h->esz));
+
+  std::vector<float> tab;
+  rope_table_host(grid, h->vae_t, hd, cfg->rope_base, h->Tc, tab);
+  h->npos = h->Tc + h->vae_t * grid * grid;
+  VLG_TRY(h->freqs.reserve(tab.size() * sizeof(float)));
+  VLG_HIP(hipMemcpy(h->freqs.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+  VLG_HIP(hipStreamCreateWithFlags(&h->s_int, hipStreamNonBlocking));
+  VLG_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+  VLG_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+  VLG_TRY(h->state.reserve(sizeof(StepState)));
+  *out = h.release();
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_destroy(vlg_gpt_t* h) {
+  if (!h) return VLG_OK;
+  (void)hipDeviceSynchronize();
+  delete h;
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_load_tensor(vlg_gpt_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                                   int32_t src_dtype, int32_t src_on_device, int32_t* consumed) {
+  VLG_CHECK(h && name && data && shape, VLG_ERR_BAD_ARG, "vlg_gpt_load_tensor: null argument");
+  if (consumed) *consumed = 0;
+  auto it = h->specs.find(name);
+  if (it == h->specs.end()) return VLG_OK;  // strict=False
+  const auto& sp = it->second;
+  bool ok = (int)sp.shape.size() == ndim;
+  int64_t n = 1;
+  for (int i = 0; ok && i < ndim; ++i) {
+    ok = shape[i] == sp.shape[i];
+    n *= shape[i];
+  }
+  VLG_CHECK(ok, VLG_ERR_BAD_SHAPE, "size mismatch for %s", name);
+  VLG_CHECK(src_dtype == VLG_F32 || src_dtype == VLG_BF16, VLG_ERR_BAD_ARG, "bad src dtype");
+  Tensor& t = h->w[sp.target];
+  const int64_t row_elems = ndim > 1 ? n / shape[0] : 1;
+  char* dst = (char*)t.buf.p + (size_t)sp.row_off * row_elems * h->esz;
+  VLG_TRY(upload_convert(dst, h->dtype, data, src_dtype, src_on_device, n, h->s_int));
+  t.loaded = true;
+  if (consumed) *consumed = 1;
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) {
+  VLG_CHECK(h && key, VLG_ERR_BAD_ARG, "vlg_gpt_set_option: null");
+  if (!strcmp(key, "graph")) {
+    h->use_graph = value != 0;
+    return VLG_OK;
+  }
+  set_error("unknown option %s", key);
+  return VLG_ERR_BAD_ARG;
+}
+
+extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* kb, double* ob) {
+  VLG_CHECK(h, VLG_ERR_BAD_ARG, "null handle");
+  if (wb) *wb = h->bytes_w;
+  if (kb) *kb = h->bytes_kv;
+  if (ob) *ob = h->bytes_other;
+  return VLG_OK;
+}
+
+namespace {
+
+template <typename T>
+struct Runner {
+  vlg_gpt* h;
+  hipStream_t st;
+  int B, Bp, N, S;
+  const float* mask;  // device [B, Tc] or null
+  StepState* state() { return h->state.as<StepState>(); }
+  template <typename U>
+  const U* W(const std::string& n) {
+    return reinterpret_cast<const U*>(h->W(n));
+  }
+
+  int linear(const T* x, const std::string& wname, T* out, float* out_f32, int M, int Nn, int K, int act) {
+    int sp = 1;
+    VLG_TRY(gemm_slabs<T>(x, W<T>(wname), h->ws.as<float>(), M, Nn, K, &sp, st));
+    return reduce_store<T>(h->ws.as<float>(), sp, out, out_f32, M, Nn, act, st);
+  }
+
+  // x [M, D] (rows m = b*Tq + t) -> xn = final-normed hidden
+  int layers(int Tq, int max_pos) {
+    const int M = Bp * Tq, D = h->D, H = h->H, hd = h->hd, F = h->F;
+    T* x = h->x.as<T>();
+    T* xn = h->xn.as<T>();
+    float* ws = h->ws.as<float>();
+    const size_t lstride = (size_t)Bp * H * S * hd;
+    VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, W<T>("layers.0.attention_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
+    for (int l = 0; l < h->L; ++l) {
+      const std::string p = "layers." + std::to_string(l) + ".";
+      int sp = 1;
+      T* kc = h->kcache.as<T>() + lstride * l;
+      T* vc = h->vcache.as<T>() + lstride * l;
+      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
+      VLG_TRY(qkv_rope_scatter<T>(ws, sp, h->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st));
+      VLG_TRY(attn_rows<T>(h->q.as<T>(), kc, vc, h->ao.as<T>(), h->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
+                           h->Tc, st));
+      VLG_TRY(gemm_slabs<T>(h->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
+      VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
+      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st));
+      VLG_TRY(reduce_silu_mul<T>(ws, sp, h->g.as<T>(), M, F, st));
+      VLG_TRY(gemm_slabs<T>(h->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st));
+      const std::string nxt = (l + 1 < h->L) ? "layers." + std::to_string(l + 1) + ".attention_norm.weight" : std::string("norm.weight");
+      VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(nxt), xn, M, D, h->cfg.norm_eps, st));
+    }
+    return VLG_OK;
+  }
+
+  // hl [Bp, D] (normed hidden of the last position) -> sampled token / latent for state->step
+  int head(const T* hl, const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
+    const int D = h->D;
+    if (h->cfg.head == VLG_HEAD_LOGITS) {
+      VLG_TRY(linear(hl, "output.weight", nullptr, h->logits.as<float>(), Bp, h->V, D, ACT_NONE));
+      return sample_rows(h->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids, h->cur_tok.as<int32_t>(), trace,
+                         nullptr, st);
+    }
+    if (h->cfg.head == VLG_HEAD_ADAPTER2) {
+      VLG_TRY(linear(hl, "vae_latent_adapter2.fc1.weight", h->t1.as<T>(), nullptr, Bp, D, D, ACT_GELU_TANH));
+      VLG_TRY(linear(h->t1.as<T>(), "vae_latent_adapter2.fc2.weight", h->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
+      return latent_head_finish<T>(h->y.as<T>(), h->cur_lat.as<float>(), out_lat, trace, state(), B, Bp, h->C, N, sp.cfg_scale,
+                                   sp.cfg_interval, st);
+    }
+    set_error("hidden (diffusion) head is not implemented yet");
+    return VLG_ERR_UNSUPPORTED;
+  }
+
+  int decode_step(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
+    const int D = h->D;
+    if (h->cfg.model_type == VLG_T2V) {
+      VLG_TRY(latent_to_rows<T>(h->cur_lat.as<float>(), h->latT.as<T>(), B, Bp, h->C, st));
+      VLG_TRY(linear(h->latT.as<T>(), "vae_latent_adapter.fc1.weight", h->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
+      VLG_TRY(linear(h->t1.as<T>(), "vae_latent_adapter.fc2.weight", h->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));
+    } else {
+      VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), h->cur_tok.as<int32_t>(), h->x.as<T>(), Bp, D, st));
+    }
+    VLG_TRY(layers(1, S - 1));
+    VLG_TRY(head(h->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
+    return advance_state(state(), st);
+  }
+
+  int prefill(const void* d_cond, const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
+    const int D = h->D, Tc = h->Tc;
+    VLG_TRY(set_state(state(), 0, 0, st));
+    if (h->cfg.model_type == VLG_C2I) {
+      VLG_TRY(gather_rows_i64<T>(W<T>("cls_embedding.embedding_table.weight"), (const int64_t*)d_cond, B, h->cfg.num_classes,
+                                 h->x.as<T>(), Bp, D, st));
+    } else {
+      const int M = Bp * Tc;
+      VLG_TRY(build_text_cond<T>((const float*)d_cond, W<T>("cls_embedding.uncond_embedding"), h->condT.as<T>(), B, Bp, Tc, h->cd, st));
+      VLG_TRY(linear(h->condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", h->t1.as<T>(), nullptr, M, D, h->cd, ACT_GELU_TANH));
+      VLG_TRY(linear(h->t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", h->x.as<T>(), nullptr, M, D, D, ACT_NONE));
+    }
+    VLG_TRY(layers(Tc, Tc - 1));
+    const T* hl = h->xn.as<T>();
+    if (Tc > 1) {
+      VLG_TRY(take_last_rows<T>(h->xn.as<T>(), h->hl.as<T>(), Bp, Tc, D, st));
+      hl = h->hl.as<T>();
+    }
+    VLG_TRY(head(hl, sp, noise, out_ids, out_lat, trace));
+    return set_state(state(), Tc, 1, st);
+  }
+};
+
+template <typename T>
+int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, int N, const vlg_sampling_params& sp,
+                  const float* d_noise, int32_t* out_ids, float* out_lat, float* trace, hipStream_t caller) {
+  const bool cfg_on = sp.cfg_scale > 1.0f;
+  const int Bp = cfg_on ? 2 * B : B;
+  const int Tc = h->Tc, D = h->D, H = h->H, hd = h->hd, F = h->F;
+  const int S = round_up(Tc + N, 8);  // gpt.py:322
+  VLG_CHECK(Tc + N <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table (%d positions after %d cond tokens)", N,
+            h->npos - Tc, Tc);
+  if (cfg_on && h->cfg.model_type != VLG_C2I)
+    VLG_CHECK(Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
+  for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
+
+  // ---- buffers (grow-only) -------------------------------------------------------------------------------
+  const int M = Bp * Tc;  // prefill rows
+  const size_t e = h->esz;
+  VLG_TRY(h->kcache.reserve((size_t)h->L * Bp * H * S * hd * e));
+  VLG_TRY(h->vcache.reserve((size_t)h->L * Bp * H * S * hd * e));
+  size_t wsf = 0;
+  auto need = [&](int m, int n, int k) { wsf = std::max(wsf, gemm_ws_floats(m, n, k, (int)e)); };
+  for (int m : {M, Bp}) {
+    need(m, 3 * D, D);
+    need(m, D, D);
+    need(m, 2 * F, D);
+    need(m, D, F);
+    need(m, D, h->cd > 0 ? h->cd : D);
+  }
+  need(Bp, h->V > 0 ? h->V : D, D);
+  need(Bp, D, h->C > 0 ? h->C : D);
+  need(Bp, h->C > 0 ? h->C : D, D);
+  VLG_TRY(h->ws.reserve(wsf * sizeof(float)));
+  VLG_TRY(h->attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
+  VLG_TRY(h->x.reserve((size_t)M * D * e));
+  VLG_TRY(h->xn.reserve((size_t)M * D * e));
+  VLG_TRY(h->q.reserve((size_t)M * D * e));
+  VLG_TRY(h->ao.reserve((size_t)M * D * e));
+  VLG_TRY(h->g.reserve((size_t)M * F * e));
+  VLG_TRY(h->t1.reserve((size_t)M * D * e));
+  VLG_TRY(h->hl.reserve((size_t)Bp * D * e));
+  if (h->cd > 0) VLG_TRY(h->condT.reserve((size_t)M * h->cd * e));
+  if (h->C > 0) {
+    VLG_TRY(h->latT.reserve((size_t)Bp * h->C * e));
+    VLG_TRY(h->y.reserve((size_t)Bp * h->C * e));
+    VLG_TRY(h->cur_lat.reserve((size_t)B * h->C * sizeof(float)));
+  }
+  if (h->V > 0) VLG_TRY(h->logits.reserve((size_t)Bp * h->V * sizeof(float)));
+  VLG_TRY(h->cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
+
+  // ---- run on the internal stream, ordered after/before the caller's stream --------------------------------
+  hipStream_t st = h->s_int;
+  VLG_HIP(hipEventRecord(h->ev_in, caller));
+  VLG_HIP(hipStreamWaitEvent(st, h->ev_in, 0));
+
+  Runner<T> r{h, st, B, Bp, N, S, d_mask};
+  VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
+  const int steps = N - 1;
+  if (steps > 0) {
+    if (h->use_graph) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = r.decode_step(sp, d_noise, out_ids, out_lat, trace);
+      hipError_t ce = hipStreamEndCapture(st, &graph);
+      if (rc != VLG_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      VLG_HIP(ce);
+      VLG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      for (int i = 0; i < steps; ++i) {
+        hipError_t le = hipGraphLaunch(exec, st);
+        if (le != hipSuccess) {
+          (void)hipGraphExecDestroy(exec);
+          (void)hipGraphDestroy(graph);
+          VLG_HIP(le);
+        }
+      }
+      VLG_HIP(hipStreamSynchronize(st));
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
+    } else {
+      for (int i = 0; i < steps; ++i) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+    }
+  }
+  VLG_HIP(hipEventRecord(h->ev_out, st));
+  VLG_HIP(hipStreamWaitEvent(caller, h->ev_out, 0));
+
+  // ---- algorithmic bytes of this call ---------------------------------------------------------
+  double P = (double)h->L * (4.0 * D * D + 3.0 * D * F);
+  if (h->cfg.head == VLG_HEAD_LOGITS) P += (double)D * h->V;
+  if (h->cfg.model_type == VLG_T2V) P += 2.0 * D * D + 2.0 * D * h->C;
+  h->bytes_w = (double)e * P * N;
+  double kv = 0;
+  for (int i = 0; i < N; ++i) {
+    const double p = (i == 0) ? (Tc - 1) : (Tc + i - 1);
+    kv += 2.0 * h->L * Bp * D * (p + 1) * e + 2.0 * h->L * Bp * D * e * (i == 0 ? Tc : 1);
+  }
+  h->bytes_kv = kv;
+  h->bytes_other = (h->cfg.head == VLG_HEAD_LOGITS) ? 4.0 * Bp * h->V * N : 0.0;
+  return VLG_OK;
+}
+
+}  // namespace
+
+extern "C" int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, int32_t B, int32_t N,
+                                const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids, float* d_out_lat,
+                                float* d_trace, void* stream) {
+  VLG_CHECK(h && d_cond && sp, VLG_ERR_BAD_ARG, "vlg_gpt_generate: null argument");
+  VLG_CHECK(B > 0 && N > 0, VLG_ERR_BAD_ARG, "vlg_gpt_generate: B and N must be positive");
+  if (h->cfg.head == VLG_HEAD_LOGITS)
+    VLG_CHECK(d_out_ids, VLG_ERR_BAD_ARG, "vlg_gpt_generate: d_out_ids is required for the logits head");
+  else
+    VLG_CHECK(d_out_lat, VLG_ERR_BAD_ARG, "vlg_gpt_generate: d_out_lat is required for a latent head");
+  if (h->dtype == VLG_BF16)
+    return generate_impl<bf16>(h, d_cond, d_emb_mask, B, N, *sp, d_noise, d_out_ids, d_out_lat, d_trace, (hipStream_t)stream);
+  return generate_impl<float>(h, d_cond, d_emb_mask, B, N, *sp, d_noise, d_out_ids, d_out_lat, d_trace, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// unit entry points
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Scratch {
+  DevBuf ws, aux, state;
+};
+Scratch& scratch() {
+  static Scratch s;
+  return s;
+}
+}  // namespace
+
+extern "C" int vlg_rmsnorm(const void* d_x, const void* d_w, void* d_out, int32_t rows, int32_t dim, float eps, int32_t dtype,
+                           void* stream) {
+  VLG_CHECK(d_x && d_w && d_out && rows > 0 && dim > 0, VLG_ERR_BAD_ARG, "vlg_rmsnorm: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  // the kernel updates h in place only when slabs are given; with ws == nullptr x is read-only
+  if (dtype == VLG_BF16)
+    return reduce_residual_rmsnorm<bf16>(nullptr, 0, (bf16*)d_x, (const bf16*)d_w, (bf16*)d_out, rows, dim, eps, st);
+  if (dtype == VLG_F32)
+    return reduce_residual_rmsnorm<float>(nullptr, 0, (float*)d_x, (const float*)d_w, (float*)d_out, rows, dim, eps, st);
+  set_error("vlg_rmsnorm: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vlg_linear(const void* d_x, const void* d_w, void* d_out, int32_t M, int32_t N, int32_t K, int32_t dtype,
+                          void* stream) {
+  VLG_CHECK(d_x && d_w && d_out && M > 0 && N > 0 && K > 0, VLG_ERR_BAD_ARG, "vlg_linear: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  VLG_HIP(hipStreamSynchronize(st));
+  Scratch& s = scratch();
+  VLG_TRY(s.ws.reserve(gemm_ws_floats(M, N, K, (int)dtype_size(dtype)) * sizeof(float)));
+  int sp = 1;
+  if (dtype == VLG_BF16) {
+    VLG_TRY(gemm_slabs<bf16>((const bf16*)d_x, (const bf16*)d_w, s.ws.as<float>(), M, N, K, &sp, st));
+    return reduce_store<bf16>(s.ws.as<float>(), sp, (bf16*)d_out, nullptr, M, N, ACT_NONE, st);
+  }
+  if (dtype == VLG_F32) {
+    VLG_TRY(gemm_slabs<float>((const float*)d_x, (const float*)d_w, s.ws.as<float>(), M, N, K, &sp, st));
+    return reduce_store<float>(s.ws.as<float>(), sp, (float*)d_out, nullptr, M, N, ACT_NONE, st);
+  }
+  set_error("vlg_linear: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vlg_sample(const float* d_logits, int32_t B, int32_t V, int32_t cfg_on, const vlg_sampling_params* sp,
+                          const float* d_noise, uint64_t step, int32_t* d_out_idx, float* d_out_probs, void* stream) {
+  VLG_CHECK(d_logits && sp && d_out_idx && B > 0 && V > 0, VLG_ERR_BAD_ARG, "vlg_sample: bad argument");
+  // unit call: output slot 0 of an N = 1 sequence; `step` only seeds the Philox stream / the cfg_interval rule
+  vlg_sampling_params p = *sp;
+  if (d_noise == nullptr) p.seed = sp->seed + 0x9E3779B97F4A7C15ull * step;
+  return sample_rows(d_logits, B, V, cfg_on != 0, p, d_noise, nullptr, 0, 1, d_out_idx, nullptr, nullptr, d_out_probs,
+                     (hipStream_t)stream);
+}
+
+extern "C" int vlg_attn_decode(const void* d_q, const void* d_k, const void* d_v, void* d_out, int32_t Bp, int32_t H, int32_t S,
+                               int32_t hd, int32_t pos, const float* d_mask, int32_t Bmask, int32_t Tc, int32_t dtype, void* stream) {
+  VLG_CHECK(d_q && d_k && d_v && d_out && Bp > 0 && H > 0 && S > 0 && pos >= 0 && pos < S, VLG_ERR_BAD_ARG,
+            "vlg_attn_decode: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  VLG_HIP(hipStreamSynchronize(st));
+  Scratch& s = scratch();
+  VLG_TRY(s.aux.reserve(attn_ws_floats(Bp, H, hd) * sizeof(float)));
+  VLG_TRY(s.state.reserve(sizeof(StepState)));
+  const StepState ss{pos, 0};
+  VLG_HIP(hipMemcpy(s.state.p, &ss, sizeof(ss), hipMemcpyHostToDevice));
+  if (dtype == VLG_BF16)
+    return attn_rows<bf16>((const bf16*)d_q, (const bf16*)d_k, (const bf16*)d_v, (bf16*)d_out, s.aux.as<float>(), s.state.as<StepState>(),
+                           Bp, 1, H, hd, S, pos, d_mask, Bmask > 0 ? Bmask : 1, Tc, st);
+  if (dtype == VLG_F32)
+    return attn_rows<float>((const float*)d_q, (const float*)d_k, (const float*)d_v, (float*)d_out, s.aux.as<float>(),
+                            s.state.as<StepState>(), Bp, 1, H, hd, S, pos, d_mask, Bmask > 0 ? Bmask : 1, Tc, st);
+  set_error("vlg_attn_decode: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}

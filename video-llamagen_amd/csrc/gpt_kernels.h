@@ -1,0 +1,79 @@
+// Launchers for the decode/prefill kernels of the GPT path (gfx950).  All asynchronous on `st`.
+#pragma once
+#include "common.h"
+
+namespace vlg {
+
+// Position/step state that lives in device memory so one captured graph serves every decode step.
+struct StepState {
+  int32_t pos;    // absolute input position of the current step's query rows (first row when Tq > 1)
+  int32_t step;   // index of the token being produced (0 = prefill output)
+};
+
+enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1 };
+
+// ---- GEMM: slabs[s][M][N] (fp32 partial sums over a K slice) = x[M,K] @ w[N,K]^T -----------------
+// returns the number of slabs written through *splits (>= 1).  `ws` must hold max_splits*M*N floats.
+template <typename T>
+int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits, hipStream_t st);
+int gemm_max_splits();
+size_t gemm_ws_floats(int M, int N, int K, int elem_size);
+
+// out[m][n] = rt(act(rt(sum_s slab[s][m][n])));  out_f32 (optional) receives float(rt(sum)) (gpt.py:371)
+template <typename T>
+int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int N, int act, hipStream_t st);
+
+// h[m] = rt(h[m] + rt(sum slabs));  hn[m] = rmsnorm(h[m]) * w      (gpt.py:257-258 + :146-148)
+// if ws == nullptr only the norm is computed (first layer).
+template <typename T>
+int reduce_residual_rmsnorm(const float* ws, int splits, T* h, const T* w, T* hn, int M, int D, float eps, hipStream_t st);
+
+// g[m][n] = rt(rt(silu(rt(sum a))) * rt(sum b)), slab rows are [w1 | w3] outputs, N2 = 2F   (gpt.py:167)
+template <typename T>
+int reduce_silu_mul(const float* ws, int splits, T* g, int M, int F, hipStream_t st);
+
+// qkv slabs [s][M][3D] -> rope(q) to qbuf [M,H,hd]; rope(k), v into the caches at pos0 + (m % Tq)
+// caches: [Bp, H, S, hd]; rows m = b*Tq + t.  freqs: fp32 [npos, hd/2, 2]          (gpt.py:215-227)
+template <typename T>
+int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache, const float* freqs,
+                     const StepState* state, int M, int Tq, int H, int hd, int S, hipStream_t st);
+
+// attention of every query row m = b*Tq + t (position p = state->pos + t) over keys 0..p of batch b
+// (gpt.py:230-237 with the mask of generate.py:156-165).  out [M, H*hd].
+// mask: fp32 [Bmask, Tc] or null; batch row b uses mask row b % Bmask.
+template <typename T>
+int attn_rows(const T* qbuf, const T* kcache, const T* vcache, T* out, float* partial_ws, const StepState* state,
+              int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
+              hipStream_t st);
+size_t attn_ws_floats(int M, int H, int hd);
+
+// embedding gathers -----------------------------------------------------------------------------
+template <typename T>
+int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, hipStream_t st);   // gpt.py:354
+template <typename T>
+int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, hipStream_t st);  // gpt.py:82 + generate.py:131
+// cond [B,Tc,cd] fp32 (+ uncond [120,cd] for the CFG half) -> T [Bp*Tc, cd]        (generate.py:138-139)
+template <typename T>
+int build_text_cond(const float* cond, const T* uncond, T* out, int B, int Bp, int Tc, int cd, hipStream_t st);
+// rows (b, Tq-1) of x [Bp*Tq, D] -> [Bp, D]
+template <typename T>
+int take_last_rows(const T* x, T* out, int Bp, int Tq, int D, hipStream_t st);
+// latent fp32 [B,C] (cur) -> T [Bp, C] (duplicated for CFG)
+template <typename T>
+int latent_to_rows(const float* cur, T* out, int B, int Bp, int C, hipStream_t st);
+// head output T [Bp, C] -> CFG combine (generate_video_diff.py:97-105) -> out_lat[b][step] fp32 and cur [B,C]
+template <typename T>
+int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp,
+                       int C, int N, float cfg_scale, int cfg_interval, hipStream_t st);
+
+int advance_state(StepState* state, hipStream_t st);
+int set_state(StepState* state, int pos, int step, hipStream_t st);
+
+// sampler (sampler.hip) -----------------------------------------------------------------------
+// logits fp32 [Bp, V]; writes out_ids[b*N + step] (if out_ids), cur_tok[b] (and [b+B] when cfg_on),
+// trace[step][b][V] (if trace), probs[b][V] (if probs).  noise: fp32 [N or 1][B][V] indexed by step.
+int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampling_params& sp, const float* noise,
+                const StepState* state, int fixed_step, int N, int32_t* out_ids, int32_t* cur_tok, float* trace,
+                float* probs, hipStream_t st);
+
+}  // namespace vlg

@@ -1,0 +1,226 @@
+"""Host mirror of the reference model object for the sampling path.
+
+Reference: autoregressive/models/gpt.py:23-50 (ModelArgs), :262-332 (Transformer, setup_caches),
+:441-470 (size registry); t2v fields gpt_video.py:58-61.  The object owns a vlg_gpt handle (weights +
+KV cache live in HBM inside libvlg); there is no torch compute here.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def find_multiple(n: int, k: int):
+    if n % k == 0:
+        return n
+    return n + k - (n % k)
+
+
+@dataclass
+class ModelArgs:
+    dim: int = 4096
+    n_layer: int = 32
+    n_head: int = 32
+    n_kv_head: Optional[int] = None
+    multiple_of: int = 256
+    ffn_dim_multiplier: Optional[float] = None
+    rope_base: float = 10000
+    norm_eps: float = 1e-5
+    initializer_range: float = 0.02
+
+    token_dropout_p: float = 0.1
+    attn_dropout_p: float = 0.0
+    resid_dropout_p: float = 0.1
+    ffn_dropout_p: float = 0.1
+    drop_path_rate: float = 0.0
+
+    num_classes: int = 1000
+    caption_dim: int = 2048
+    class_dropout_prob: float = 0.1
+    model_type: str = 'c2i'
+
+    vocab_size: int = 16384
+    cls_token_num: int = 1
+    block_size: int = 256
+    max_batch_size: int = 32
+    max_seq_len: int = 2048
+
+    # t2v (gpt_video.py:58-61)
+    vae_embed_dim: int = 2048
+    t_downsample_size: int = 4
+    num_frames: int = 17
+    head: str = 'auto'     # 'logits' | 'adapter2' (gpt_video.py:296,431) | 'hidden' (gpt_video_diff.py:657)
+
+
+class _Embedding:
+    """stand-in for `model.tok_embeddings.weight.dtype` (generate.py:154)"""
+
+    class _W:
+        def __init__(self):
+            self.dtype = torch.float32
+
+    def __init__(self):
+        self.weight = self._W()
+
+
+class _ClsEmbedding:
+    """exposes `.uncond_embedding` (generate.py:138)"""
+
+    def __init__(self):
+        self.uncond_embedding = None
+
+
+class Transformer:
+    """Drop-in for the inference surface of gpt.py `Transformer`."""
+
+    def __init__(self, config: ModelArgs):
+        if config.n_kv_head is not None and config.n_kv_head != config.n_head:
+            raise L.VlgError(-3, "n_kv_head != n_head is not used by any reference size (gpt.py:441-464)")
+        if config.ffn_dim_multiplier is not None:
+            raise L.VlgError(-3, "ffn_dim_multiplier is not used by any reference size")
+        if config.model_type not in ('c2i', 't2i', 't2v'):
+            raise Exception("please check model type")          # gpt.py:277
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.n_layer = config.n_layer
+        self.block_size = config.block_size
+        self.num_classes = config.num_classes
+        self.model_type = config.model_type
+        self.cls_token_num = config.cls_token_num
+        self.num_frames = config.num_frames
+        self.t_downsample_size = config.t_downsample_size
+        grid_size = int(self.block_size ** 0.5)
+        assert grid_size * grid_size == self.block_size
+        self.tok_embeddings = _Embedding()
+        self.cls_embedding = _ClsEmbedding()
+        self.max_batch_size = -1
+        self.max_seq_length = -1
+        self.causal_mask = None
+        self.training = False
+        self._dtype = torch.float32
+        self._device = None
+        self._handle = None
+        self._loaded = set()
+        self.use_graph = True
+
+    # ---- nn.Module-like surface ---------------------------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        if dtype is not None and dtype != self._dtype:
+            if self._handle is not None:
+                raise L.VlgError(-6, "dtype must be chosen before weights are loaded")
+            L.torch_dtype_code(dtype)
+            self._dtype = dtype
+            self.tok_embeddings.weight.dtype = dtype
+        if device is not None:
+            self._device = torch.device(device)
+        return self
+
+    def _head_code(self):
+        h = self.config.head
+        if h == 'auto':
+            h = 'adapter2' if self.model_type == 't2v' else 'logits'
+        return {'logits': L.VLG_HEAD_LOGITS, 'adapter2': L.VLG_HEAD_ADAPTER2, 'hidden': L.VLG_HEAD_HIDDEN}[h]
+
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return
+        if self._device is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        if self._device.type != "cuda":
+            raise L.VlgError(-3, "video_llamagen_amd runs on an MI355X only (device %s requested)" % self._device)
+        c = self.config
+        cfg = L.GptConfig(
+            dim=c.dim, n_layer=c.n_layer, n_head=c.n_head, vocab_size=c.vocab_size, block_size=c.block_size,
+            cls_token_num=c.cls_token_num, model_type={'c2i': L.VLG_C2I, 't2i': L.VLG_T2I, 't2v': L.VLG_T2V}[c.model_type],
+            num_classes=c.num_classes, caption_dim=c.caption_dim if c.model_type != 'c2i' else 0,
+            vae_embed_dim=c.vae_embed_dim if c.model_type == 't2v' else 0, num_frames=c.num_frames,
+            t_downsample_size=c.t_downsample_size, head=self._head_code(), dtype=L.torch_dtype_code(self._dtype),
+            multiple_of=c.multiple_of, norm_eps=c.norm_eps, rope_base=float(c.rope_base))
+        h = C.c_void_p()
+        with torch.cuda.device(self._device):
+            L.check(L.lib().vlg_gpt_create(C.byref(cfg), C.byref(h)))
+        self._handle = h
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference key names.  Returns (missing, unexpected) like torch."""
+        self._ensure_handle()
+        unexpected = []
+        with torch.cuda.device(self._device):
+            for k, v in state_dict.items():
+                if L.load_tensor(L.lib().vlg_gpt_load_tensor, self._handle, k, v):
+                    self._loaded.add(k)
+                    if k == "cls_embedding.uncond_embedding":
+                        self.cls_embedding.uncond_embedding = v
+                else:
+                    unexpected.append(k)
+        if strict and unexpected:
+            raise RuntimeError("Unexpected key(s) in state_dict: %s" % ", ".join(unexpected))
+        return [], unexpected
+
+    def setup_caches(self, max_batch_size, max_seq_length, dtype=None):
+        """gpt.py:318-332.  The KV cache itself is (re)sized inside vlg_gpt_generate; this records the shape."""
+        self.max_seq_length = find_multiple(max_seq_length, 8)
+        self.max_batch_size = max_batch_size
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                L.lib().vlg_gpt_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def algorithmic_bytes(self):
+        w, k, o = C.c_double(), C.c_double(), C.c_double()
+        L.check(L.lib().vlg_gpt_last_algorithmic_bytes(self._handle, C.byref(w), C.byref(k), C.byref(o)))
+        return w.value, k.value, o.value
+
+
+#################################################################################
+#                                GPT Configs (gpt.py:441-470)                   #
+#################################################################################
+def GPT_7B(**kwargs):
+    return Transformer(ModelArgs(n_layer=32, n_head=32, dim=4096, **kwargs))
+
+
+def GPT_3B(**kwargs):
+    return Transformer(ModelArgs(n_layer=24, n_head=32, dim=3200, **kwargs))
+
+
+def GPT_1B(**kwargs):
+    return Transformer(ModelArgs(n_layer=22, n_head=32, dim=2048, **kwargs))
+
+
+def GPT_XXXL(**kwargs):
+    return Transformer(ModelArgs(n_layer=48, n_head=40, dim=2560, **kwargs))
+
+
+def GPT_XXL(**kwargs):
+    return Transformer(ModelArgs(n_layer=48, n_head=24, dim=1536, **kwargs))
+
+
+def GPT_XL(**kwargs):
+    return Transformer(ModelArgs(n_layer=36, n_head=20, dim=1280, **kwargs))
+
+
+def GPT_L(**kwargs):
+    return Transformer(ModelArgs(n_layer=24, n_head=16, dim=1024, **kwargs))
+
+
+def GPT_B(**kwargs):
+    return Transformer(ModelArgs(n_layer=12, n_head=12, dim=768, **kwargs))
+
+
+GPT_models = {
+    'GPT-B': GPT_B, 'GPT-L': GPT_L, 'GPT-XL': GPT_XL, 'GPT-XXL': GPT_XXL, 'GPT-XXXL': GPT_XXXL,
+    'GPT-1B': GPT_1B, 'GPT-3B': GPT_3B, 'GPT-7B': GPT_7B,
+}
