@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GPT-XL text-to-video token sampling (+ CausalVideoVAE decode), 17 frames @ 256x256.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch of synthetic conditions on every rank:
+prefill (120 text tokens) + 5119 KV-cached decode steps for `--batch` videos (5 x 32 x 32 latent tokens each,
+BASELINE config 4 / SURVEY.md §8d "C4 ds 8"), the CausalVideoVAE decode of those latents to 17 x 256 x 256
+frames, and (N > 1) the one RCCL all-gather of the results.  Batch shards are independent: per-GPU work is
+fixed as N grows ("weak").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_gpt(V, a, device):
+    m = V.GPT_models[a.gpt_model](block_size=a.latent ** 2, cls_token_num=120, model_type="t2v",
+                                  vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4,
+                                  caption_dim=2048)
+    m.to(device=device, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).eval()
+    c = m.config
+    D = c.dim
+    F = (int(2 * 4 * D / 3) + 255) // 256 * 256
+    g = torch.Generator(device=device).manual_seed(1234)
+
+    def rnd(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std)
+
+    sd = {"cls_embedding.cap_proj.fc1.weight": rnd(D, 2048), "cls_embedding.cap_proj.fc2.weight": rnd(D, D),
+          "cls_embedding.uncond_embedding": rnd(120, 2048, std=2048 ** -0.5),
+          "vae_latent_adapter.fc1.weight": rnd(D, a.vae_embed_dim, std=0.3), "vae_latent_adapter.fc2.weight": rnd(D, D),
+          "vae_latent_adapter2.fc1.weight": rnd(D, D), "vae_latent_adapter2.fc2.weight": rnd(a.vae_embed_dim, D, std=0.3),
+          "norm.weight": 1 + rnd(D, std=0.1)}
+    m.load_state_dict(sd, strict=False)
+    for i in range(c.n_layer):
+        p = f"layers.{i}."
+        m.load_state_dict({p + "attention.wqkv.weight": rnd(3 * D, D), p + "attention.wo.weight": rnd(D, D),
+                           p + "feed_forward.w1.weight": rnd(F, D), p + "feed_forward.w3.weight": rnd(F, D),
+                           p + "feed_forward.w2.weight": rnd(D, F), p + "attention_norm.weight": 1 + rnd(D, std=0.1),
+                           p + "ffn_norm.weight": 1 + rnd(D, std=0.1)}, strict=False)
+    return m
+
+
+def synth_cond(B, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    emb = torch.randn(B, 120, 2048, generator=g) * 0.1
+    lens = torch.randint(8, 121, (B,), generator=g)
+    mask = torch.zeros(B, 120)
+    for b in range(B):
+        mask[b, 120 - int(lens[b]):] = 1.0              # left padding (sample_t2i.py:105-119)
+    return (emb * mask[:, :, None]).to(device), mask.to(device)
+
+
+def cpu_baseline(a):
+    """The numpy oracle (a port, not the reference) on the host cores, on a bounded sample of the same workload:
+    GPT-XL t2v fp32, same shapes, batch `cb`, prefill + a few decode steps."""
+    import threadpoolctl  # noqa: F401  (numpy BLAS thread count is reported)
+    from oracle import cases, detweights
+    from oracle import vlg_oracle as O
+    cb, nsteps = 4, 6
+    cfg = dict(cases.GPT_SIZES[a.gpt_model], vocab_size=16384, block_size=a.latent ** 2, cls_token_num=120, model_type="t2v",
+               num_classes=1000, caption_dim=2048, norm_eps=1e-5, rope_base=10000.0, multiple_of=256,
+               vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4, head="adapter2",
+               adapter_in_std=0.3, adapter_out_std=0.3)
+    sd = detweights.gpt_weights(cfg)
+    m = O.GPTOracle(cfg, sd, "fp32")
+    c, mk = cases.text_cond(cb, 120, 2048)
+    t0 = time.time()
+    O.generate_t2v(m, c, nsteps, mk)
+    dt = time.time() - t0
+    try:
+        cores = threadpoolctl.threadpool_info()[0]["num_threads"]
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": cb * nsteps / dt, "unit": "video tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"numpy oracle, {a.gpt_model} t2v fp32, batch {cb}, prefill(120)+{nsteps - 1} decode steps "
+                      f"({cb * nsteps} tokens at positions 120..{120 + nsteps - 1}) in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="videos per GPU")
+    ap.add_argument("--gpt-model", default="GPT-XL")
+    ap.add_argument("--latent", type=int, default=32, help="latent grid (256 px / downsample 8)")
+    ap.add_argument("--num-frames", type=int, default=17)
+    ap.add_argument("--vae-embed-dim", type=int, default=8)
+    ap.add_argument("--new-tokens", type=int, default=0, help="debug: generate fewer than vae_t*latent^2 tokens")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--cfg-scale", type=float, default=1.0)
+    ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import video_llamagen_amd as V
+    vae_t = (a.num_frames - 1) // 4 + 1
+    N = a.new_tokens or vae_t * a.latent ** 2
+    full = N == vae_t * a.latent ** 2
+    B = a.batch
+    gpt = build_gpt(V, a, device)
+    cond, mask = synth_cond(B, device, seed=1 + rank)
+    vae = None
+    if not a.no_vae and full and hasattr(V, "VAE_models"):
+        vae = V.bench_vae(a, device)
+
+    def step():
+        lat = V.generate_t2v(gpt, cond, N, mask, cfg_scale=a.cfg_scale)
+        out = lat
+        if vae is not None:
+            z = lat.view(B, vae_t, a.latent, a.latent, a.vae_embed_dim).permute(0, 4, 1, 2, 3).contiguous()
+            out = vae.decode(z)                          # sample_t2v_1f_diff.py:175-181
+        if world > 1:
+            gathered = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=device)
+            dist.all_gather_into_tensor(gathered, out.contiguous())
+            out = gathered
+        return out
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_gen = 0.0
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    tokens = world * B * N * a.steps
+    res = {
+        "metric": "video tokens/sec (whole job) for GPT-XL t2v 17f@256 sampling + VAE decode",
+        "value": tokens / dt, "unit": "video tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"{a.gpt_model} t2v (adapter2 head), 120 text tokens + {N} latent tokens "
+                               f"({vae_t}x{a.latent}x{a.latent}, vae_embed_dim {a.vae_embed_dim}), cfg {a.cfg_scale}, "
+                               f"{B} videos per GPU, {'CausalVideoVAE decode to 17x256x256 included' if vae is not None else 'VAE decode NOT included'}",
+                   "global_batch": world * B, "seq_len": 120 + N, "parallelism": f"batch-shard x{world}"},
+        "frames_per_s": (world * B * a.num_frames * a.steps / dt) if vae is not None else None,
+        "tokens_per_s_per_gpu": tokens / dt / world,
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel = split-KV decode attention (reads K,V rows 0..p of one layer).  Extra eager pass with HIP
+        # events on the library's launch stream around layer 0's attention kernel of every decode step.
+        gpt.time_attn = True
+        V.generate_t2v(gpt, cond, N, mask, cfg_scale=a.cfg_scale)
+        torch.cuda.synchronize()
+        gpt.time_attn = False
+        ms, by, n = gpt.attn_timing()
+        if n > 0 and ms > 0:
+            ach = by / (ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "attn_partial_kernel", "launches_timed": n,
+                               "avg_launch_us": 1e3 * ms / n, "avg_algorithmic_bytes_per_launch": by / n}
+        wb, kb, ob = gpt.algorithmic_bytes()
+        res["algorithmic_bytes_per_step"] = {"weights": wb, "kv": kb, "other": ob}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(a)
+        except Exception as e:  # reported, never fatal for the GPU numbers
+            res["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,8 +92,12 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
 
 /* bytes the last generate() call moved algorithmically (weights + KV read/write + logits), for roofline */
 int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* kv_bytes, double* other_bytes);
-/* use HIP graph replay for the decode loop (default 1) */
+/* options: "graph" (default 1) = HIP-graph replay of the decode step; "time_attn" (default 0) = eager decode loop
+ * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step   */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
+/* event-timed attention launches of the last generate() with time_attn=1: total ms, total algorithmic KV bytes
+ * (2 * Bp * D * (p+1) * elem per launch), number of launches                                                      */
+int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches);
 
 /* ------------------------------------------------------------------------------------------
  * Unit entry points (parity tests call the very kernels the handle uses)

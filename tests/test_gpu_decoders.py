@@ -1,0 +1,135 @@
+"""GPU parity of the VQ-16 image decoder, the CausalVideoVAE decoder and the codebook nearest-neighbour kernels
+against the reference-generated goldens (tests/golden/{vq,vae}.npz) and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, detweights
+from oracle import vlg_oracle as O
+from vlg_testutil import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _vq(dtype):
+    import video_llamagen_amd as V
+    m = V.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).to("cuda", dtype).eval()
+    sd = detweights.vq_weights()
+    _, skipped = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert skipped == []
+    return m, sd
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_vq_decode_code(golden, dt):
+    g = golden("vq")
+    m, _ = _vq(torch.float32 if dt == "fp32" else torch.bfloat16)
+    code = cases.rng(21).integers(0, 16384, size=(2, 16)).astype(np.int64)
+    img = m.decode_code(torch.from_numpy(code), [2, 8, 4, 4])
+    ref = g["vq_decode_g4"]
+    assert tuple(img.shape) == ref.shape == (2, 3, 64, 64) and img.dtype == torch.float32
+    # fp32 handle: accumulation-order noise only.  bf16 handle: bf16 activations/weights through 58 convs, fp32 accumulate;
+    # stated tolerance 4e-2 of the output range (max |pixel|), rms error 1e-2.
+    err = np.abs(to_np(img) - ref)
+    scale = np.abs(ref).max()
+    if dt == "fp32":
+        assert err.max() < 2e-3 * scale
+    else:
+        assert err.max() < 4e-2 * scale and np.sqrt((err ** 2).mean()) < 1e-2 * scale
+
+
+def test_vq_decode_g16_matches_oracle_stats():
+    """BASELINE config-1 image size (16x16 tokens -> 256 px), B=1, fp32 handle vs the numpy oracle."""
+    m, sd = _vq(torch.float32)
+    code = cases.rng(23).integers(0, 16384, size=(1, 256)).astype(np.int64)
+    img = to_np(m.decode_code(torch.from_numpy(code), [1, 8, 16, 16]))
+    ref = O.VQOracle(sd).decode_code(code, [1, 8, 16, 16])
+    assert img.shape == (1, 3, 256, 256)
+    assert np.abs(img - ref).max() < 2e-3 * np.abs(ref).max()
+
+
+def test_vq_argmin(golden):
+    g = golden("vq")
+    m, sd = _vq(torch.bfloat16)
+    z = cases.rng(22).standard_normal((2, 8, 6, 6), dtype=np.float32)
+    idx = m.quantize_indices(torch.from_numpy(z)).cpu().numpy()
+    assert (idx == g["vq_argmin"]).mean() > 0.98      # near-ties may flip (reduction order), exact ties may not:
+    import video_llamagen_amd as V
+    m2 = V.VQ_models["VQ-16"]().to("cuda").eval()
+    E = sd["quantize.embedding.weight"].copy()
+    E[777] = E[5]
+    m2.load_state_dict({"quantize.embedding.weight": torch.from_numpy(E)})
+    zz = O.l2norm_rows(E[[5, 5, 9]]).reshape(1, 3, 1, 8).transpose(0, 3, 1, 2).copy()
+    idx2 = m2.quantize_indices(torch.from_numpy(zz)).cpu().numpy()
+    assert (idx2 == g["vq_argmin_tie"]).all() and idx2[0] == 5   # first minimum wins (Q11)
+    # size-independent property at a full-size grid: every codebook row is its own nearest neighbour
+    ids = cases.rng(5).integers(0, 16384, size=(4 * 24 * 24,))
+    En = O.l2norm_rows(sd["quantize.embedding.weight"])
+    zq = En[ids].reshape(4, 24, 24, 8).transpose(0, 3, 1, 2).copy()
+    back = m.quantize_indices(torch.from_numpy(zq)).cpu().numpy()
+    d_self = ((En[back] - En[ids]) ** 2).sum(-1)
+    assert (back == ids).mean() > 0.999 and d_self.max() < 1e-6
+
+
+def test_video_codebook_argmin():
+    import video_llamagen_amd as V
+    r = cases.rng(41)
+    E = r.standard_normal((2048, 256), dtype=np.float32)
+    z = r.standard_normal((2, 256, 2, 4, 4), dtype=np.float32)
+    flat = np.moveaxis(z, 1, -1).reshape(-1, 256)
+    idx = V.codebook_argmin(torch.from_numpy(flat).cuda(), torch.from_numpy(E).cuda()).cpu().numpy()
+    ref, d = O.video_codebook_argmin(z, E)
+    ref = ref.reshape(-1)
+    gap = np.sort(d, -1)
+    ok = (idx == ref) | ((gap[:, 1] - gap[:, 0]) < 1e-3)
+    assert ok.all() and (idx == ref).mean() > 0.97
+    # exact recovery of codebook rows
+    ids = r.integers(0, 2048, size=(500,))
+    assert (V.codebook_argmin(torch.from_numpy(E[ids]).cuda(), torch.from_numpy(E).cuda()).cpu().numpy() == ids).all()
+
+
+def _vae(dtype):
+    import video_llamagen_amd as V
+    cfg = cases.TINY_VAE
+    m = V.VAE_models["VAE-16"](hidden_size=cfg["hidden_size"], z_channels=cfg["z_channels"], embed_dim=cfg["embed_dim"],
+                               hidden_size_mult=cfg["hidden_size_mult"], num_res_blocks=cfg["num_res_blocks"]).to("cuda", dtype)
+    sd = detweights.vae_weights(cfg)
+    _, skipped = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert skipped == []
+    return m
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_vae_decode(golden, dt):
+    g = golden("vae")
+    cfg = cases.TINY_VAE
+    m = _vae(torch.float32 if dt == "fp32" else torch.bfloat16)
+    m.enable_tiling()
+    z = cases.rng(31).standard_normal((1, cfg["embed_dim"], 3, 4, 4), dtype=np.float32)
+    y = to_np(m.decode(torch.from_numpy(z)))
+    ref = g["vae_decode"]
+    assert y.shape == ref.shape == (1, 3, 9, 32, 32)           # Q13: 3 latent frames -> 5 -> 9
+    z1 = cases.rng(32).standard_normal((2, cfg["embed_dim"], 1, 4, 4), dtype=np.float32)
+    y1 = to_np(m.decode(torch.from_numpy(z1)))
+    ref1 = g["vae_decode_1f"]
+    for a, r_ in ((y, ref), (y1, ref1)):
+        err = np.abs(a - r_)
+        scale = np.abs(r_).max()
+        if dt == "fp32":
+            assert err.max() < 2e-3 * scale
+        else:
+            assert err.max() < 5e-2 * scale and np.sqrt((err ** 2).mean()) < 1.5e-2 * scale
+
+
+def test_vae_errors():
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib
+    m = _vae(torch.bfloat16)
+    with pytest.raises(_lib.VlgError):
+        m.decode(torch.zeros(1, 3, 1, 4, 4))
+    m.enable_tiling()
+    with pytest.raises(_lib.VlgError, match="tiled_decode"):
+        m.decode(torch.zeros(1, 8, 6, 4, 4))
+    m2 = V.VAE_models["VAE-16"](hidden_size=32, embed_dim=8).to("cuda")
+    with pytest.raises(_lib.VlgError, match="never loaded"):
+        m2.decode(torch.zeros(1, 8, 1, 4, 4))

@@ -1,0 +1,55 @@
+// Kernels shared by the VQ-16 image decoder and the CausalVideoVAE decoder (gfx950).
+// Activations are channels-last [B, T, H, W, C] (T = 1 for images) in the handle dtype.
+#pragma once
+#include "common.h"
+
+namespace vlg {
+
+struct ConvDesc {
+  int B, Ti, Hi, Wi, Cin;   // input (before the optional nearest 2x upsample)
+  int To, Ho, Wo, Cout;     // output
+  int kt, kh, kw;           // kernel; zero pad kh/2, kw/2 in H/W; causal replicate pad (kt-1) frames in front (conv.py:124-130)
+  int up;                   // 1: nearest 2x on H and W applied to the input first (vq_model.py:375; updownsample.py:146-153)
+};
+
+// out = conv(in) + bias (+ residual).  w: [Cout][taps][Cin] (re-laid out at load time), bias fp32 [Cout].
+// out_cl (channels-last, dtype T) or out_planar (fp32 [B, Cout, To, Ho, Wo], the API output layout); one must be null.
+template <typename T>
+int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl,
+                 float* out_planar, hipStream_t st);
+
+// GroupNorm(32 groups, eps) statistics + apply (+ swish) on channels-last data (vq_model.py:354-364, normalize.py:14-17)
+// stats: double [B][32][2] scratch (zeroed inside).
+template <typename T>
+int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
+               bool swish, hipStream_t st);
+
+// single-head spatial self-attention per frame (vq_model.py:335-347, attention.py:60-70): q,k,v,out [NF][HW][C], scale C^-0.5
+template <typename T>
+int spatial_attention(const T* q, const T* k, const T* v, T* out, int NF, int HW, int C, hipStream_t st);
+
+// Q12 reinterpretation of AttnBlock3D (attention.py:60-63,69): channels-last view of the reference's
+// [b,c,t,h,w] -> [b*t, c, h*w] reshape.  inverse = false: x[b][t][hw][c] -> y[b][t'][hw][c'];  inverse = true: back.
+template <typename T>
+int q12_permute(const T* x, T* y, int B, int T_, int HW, int C, bool inverse, hipStream_t st);
+
+// TimeUpsample2x (updownsample.py:189-194): [B,T,HW,C] -> [B,2T-1,HW,C]
+template <typename T>
+int time_upsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st);
+
+// layout / dtype glue
+template <typename T>
+int planar_f32_to_cl(const float* x, T* y, int B, int C, long long P, hipStream_t st);   // [B,C,P] fp32 -> [B,P,C] T
+// conv weight [Cout, Cin, taps] (reference layout, any float dtype already converted to fp32) -> [Cout][taps][Cin] T
+template <typename T>
+int relayout_conv_weight(const float* src, T* dst, int Cout, int Cin, int taps, hipStream_t st);
+// codebook lookup vq_model.py:261-276: out[b][pos][:] = normalize(E)[codes[b][pos]] (channels-last), E fp32 [n_e, e_dim]
+template <typename T>
+int codebook_lookup(const float* E, const int32_t* codes, T* out, long long n, int n_e, int e_dim, bool l2norm, hipStream_t st);
+
+// nearest-neighbour search: idx[i] = argmin_j |z_i|^2 + |e_j|^2 - 2 z_i.e_j  (first minimum).
+// l2norm: both sides row-normalised first (vq_model.py:221-232); z row i at z + i*z_stride_row + c*z_stride_c
+int codebook_argmin(const float* z, long long z_stride_row, long long z_stride_c, long long rows_per_batch, long long z_stride_batch,
+                    const float* E, long long n, int n_e, int dim, bool l2norm, int32_t* idx, hipStream_t st);
+
+}  // namespace vlg

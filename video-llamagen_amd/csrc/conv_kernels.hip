@@ -1,0 +1,617 @@
+// Conv / GroupNorm / spatial-attention kernels for the VQ-16 and CausalVideoVAE decoders (gfx950).
+//
+// Reference behaviour: tokenizer/tokenizer_image/vq_model.py:279-378 (ResnetBlock, AttnBlock, Normalize, Upsample),
+// CausalVideoVAE/causalvideovae/model/modules/conv.py:76-130 (CausalConv3d), resnet_block.py:140-172,
+// attention.py:40-76 (AttnBlock3D, Q12 reshape), updownsample.py:124-153,182-194, normalize.py:14-17.
+//
+// Convolution = implicit GEMM on MFMA (v_mfma_f32_32x32x16_bf16): M = output positions (channels-last, so one
+// position's Cin slice is contiguous), N = Cout, K = taps x Cin.  The causal time pad (replicate frame 0), the zero
+// H/W pad and the nearest-2x upsample are index arithmetic in the A-tile gather - no padded or upsampled tensor is ever
+// materialised.  128 x BN x 32 tiles, LDS double buffer with register-staged prefetch (global loads of step k+1 are in
+// flight while step k computes), 16-byte-chunk XOR swizzle so ds_read_b128 fragment reads are conflict-free.
+#include "conv_kernels.h"
+
+namespace vlg {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float swish_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// implicit-GEMM convolution, bf16
+// ---------------------------------------------------------------------------------------------------------------
+struct PosDec {
+  int b, t, y, x;
+  bool ok;
+};
+
+__device__ __forceinline__ PosDec decode_pos(long long p, const ConvDesc& d, long long ptot) {
+  PosDec r;
+  r.ok = p < ptot;
+  if (!r.ok) p = 0;
+  r.x = (int)(p % d.Wo);
+  p /= d.Wo;
+  r.y = (int)(p % d.Ho);
+  p /= d.Ho;
+  r.t = (int)(p % d.To);
+  r.b = (int)(p / d.To);
+  return r;
+}
+
+// element offset of the input row feeding output position `pd` through tap (a,i,j), or -1 (zero padding)
+__device__ __forceinline__ long long tap_src(const PosDec& pd, const ConvDesc& d, int a, int i, int j) {
+  int ti = pd.t + a - (d.kt - 1);
+  ti = ti < 0 ? 0 : ti;                                   // causal: frame 0 replicated in front (conv.py:126-129)
+  const int uy = pd.y + i - d.kh / 2, ux = pd.x + j - d.kw / 2;
+  if (!pd.ok || uy < 0 || ux < 0 || uy >= d.Ho || ux >= d.Wo) return -1;   // zero pad of nn.Conv (stride 1, "same")
+  const int iy = uy >> d.up, ix = ux >> d.up;             // nearest 2x upsample folded in
+  return ((((long long)pd.b * d.Ti + ti) * d.Hi + iy) * d.Wi + ix) * d.Cin;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* __restrict__ in, const bf16* __restrict__ w,
+                                                        const float* __restrict__ bias, const bf16* __restrict__ residual,
+                                                        bf16* __restrict__ out_cl, float* __restrict__ out_planar) {
+  constexpr int BM = 128;
+  constexpr int WM = (BN == 128) ? 64 : 32, WN = (BN == 128) ? 64 : 32;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int BCH = BN * 4 / 256;  // B chunks per thread (2 for BN=128, 0.5 -> handled by predicate for BN=32)
+  __shared__ uint4 As[2][BM * 4];
+  __shared__ uint4 Bs[2][BN * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = (BN == 128) ? (wave >> 1) : wave, wave_n = (BN == 128) ? (wave & 1) : 0;
+  const long long ptot = (long long)d.B * d.To * d.Ho * d.Wo;
+  const long long pos0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int taps = d.kt * d.kh * d.kw;
+  const int ncc = d.Cin / 32;
+  const int nk = taps * ncc;
+
+  // loader roles
+  PosDec pd[2];
+  int arow[2], ach[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    arow[i] = c >> 2;
+    ach[i] = c & 3;
+    pd[i] = decode_pos(pos0 + arow[i], d, ptot);
+  }
+  constexpr int NBL = (BCH >= 1) ? BCH : 1;
+  int brow[NBL], bch[NBL];
+  bool bok[NBL];
+#pragma unroll
+  for (int i = 0; i < NBL; ++i) {
+    const int c = tid + 256 * i;
+    brow[i] = c >> 2;
+    bch[i] = c & 3;
+    bok[i] = (c < BN * 4);
+  }
+
+  uint4 ra[2], rb[NBL];
+  auto gload = [&](int ks) {
+    const int tap = ks / ncc, cc = ks - tap * ncc;
+    const int a = tap / (d.kh * d.kw), rem = tap - a * (d.kh * d.kw);
+    const int ii = rem / d.kw, jj = rem - ii * d.kw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long src = tap_src(pd[i], d, a, ii, jj);
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (src >= 0) ra[i] = *reinterpret_cast<const uint4*>(in + src + cc * 32 + ach[i] * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      rb[i] = make_uint4(0, 0, 0, 0);
+      const int co = n0 + brow[i];
+      if (bok[i] && co < d.Cout) rb[i] = *reinterpret_cast<const uint4*>(w + ((size_t)co * taps + tap) * d.Cin + cc * 32 + bch[i] * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) As[buf][arow[i] * 4 + (ach[i] ^ ((arow[i] >> 2) & 3))] = ra[i];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i)
+      if (bok[i]) Bs[buf][brow[i] * 4 + (bch[i] ^ ((brow[i] >> 2) & 3))] = rb[i];
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int r32 = lane & 31, hh = lane >> 5;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) gload(ks + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wave_m * WM + mi * 32 + r32;
+        af[mi] = __builtin_bit_cast(bf16x8_t, As[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wave_n * WN + ni * 32 + r32;
+        bfr[ni] = __builtin_bit_cast(bf16x8_t, Bs[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (ks + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: + bias (+ residual) -> channels-last bf16 or planar fp32
+  const long long pper = (long long)d.To * d.Ho * d.Wo;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int co = n0 + wave_n * WN + ni * 32 + r32;
+      const float bv = (co < d.Cout && bias) ? bias[co] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int prow = wave_m * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const long long p = pos0 + prow;
+        if (p < ptot && co < d.Cout) {
+          float v = acc[mi][ni][e] + bv;
+          if (residual) v += bf16_to_f32(residual[p * d.Cout + co].v);
+          if (out_cl)
+            out_cl[p * d.Cout + co].v = f32_to_bf16(v);
+          else
+            out_planar[((p / pper) * d.Cout + co) * pper + (p % pper)] = v;
+        }
+      }
+    }
+  }
+}
+
+// direct convolution for layers the MFMA kernel does not tile (Cin % 32 != 0: z_channels / codebook_embed_dim inputs)
+// and for the fp32 handle dtype (parity tests at toy sizes).  One thread per (position, cout).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_naive_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+                                                         const float* __restrict__ bias, const T* __restrict__ residual,
+                                                         T* __restrict__ out_cl, float* __restrict__ out_planar) {
+  const long long ptot = (long long)d.B * d.To * d.Ho * d.Wo;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= ptot * d.Cout) return;
+  const long long p = gid / d.Cout;
+  const int co = (int)(gid % d.Cout);
+  const PosDec pd = decode_pos(p, d, ptot);
+  const int taps = d.kt * d.kh * d.kw;
+  float acc = 0.f;
+  int tap = 0;
+  for (int a = 0; a < d.kt; ++a)
+    for (int i = 0; i < d.kh; ++i)
+      for (int j = 0; j < d.kw; ++j, ++tap) {
+        const long long src = tap_src(pd, d, a, i, j);
+        if (src < 0) continue;
+        const T* xi = in + src;
+        const T* wi = w + ((size_t)co * taps + tap) * d.Cin;
+        for (int c = 0; c < d.Cin; ++c) acc = fmaf(DT<T>::ld(xi + c), DT<T>::ld(wi + c), acc);
+      }
+  float v = acc + (bias ? bias[co] : 0.f);
+  if (residual) v += DT<T>::ld(residual + p * d.Cout + co);
+  const long long pper = (long long)d.To * d.Ho * d.Wo;
+  if (out_cl)
+    DT<T>::st(out_cl + p * d.Cout + co, v);
+  else
+    out_planar[((p / pper) * d.Cout + co) * pper + (p % pper)] = v;
+}
+
+template <typename T>
+int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl, float* out_planar,
+                 hipStream_t st) {
+  if ((out_cl == nullptr) == (out_planar == nullptr)) {
+    set_error("conv_forward: exactly one output must be given");
+    return VLG_ERR_BAD_ARG;
+  }
+  const long long ptot = (long long)d.B * d.To * d.Ho * d.Wo;
+  if constexpr (sizeof(T) == 2) {
+    if (d.Cin % 32 == 0) {
+      const bool wide = (d.Cout % 128 == 0);
+      const int bn = wide ? 128 : 32;
+      dim3 grid((unsigned)cdiv64(ptot, 128), (unsigned)cdiv(d.Cout, bn));
+      if (wide)
+        conv_mfma_kernel<128><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+      else
+        conv_mfma_kernel<32><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+      return VLG_OK;
+    }
+  }
+  const long long total = ptot * d.Cout;
+  conv_naive_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+  return VLG_OK;
+}
+template int conv_forward<float>(const ConvDesc&, const float*, const float*, const float*, const float*, float*, float*, hipStream_t);
+template int conv_forward<bf16>(const ConvDesc&, const bf16*, const bf16*, const float*, const bf16*, bf16*, float*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups) + optional swish, channels-last
+//   thread -> fixed 8-channel vector (cv = tid % (C/8)), sweeps positions; per-group fp32 partials in LDS, one double
+//   atomicAdd per (workgroup, group) into stats[b][g][{sum, sumsq}].
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, long long P, int C,
+                                                       int pos_per_block) {
+  __shared__ float sm[32][2];
+  const int b = blockIdx.y;
+  const int nvec = C / VW;                // vectors per position
+  const int lanes_p = 256 / nvec;         // positions handled in parallel
+  const int cv = threadIdx.x % nvec, pl = threadIdx.x / nvec;
+  const int cg = C / 32;
+  if (threadIdx.x < 64) sm[threadIdx.x >> 1][threadIdx.x & 1] = 0.f;
+  __syncthreads();
+  float s[VW], q[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) s[e] = q[e] = 0.f;
+  const long long p0 = (long long)blockIdx.x * pos_per_block;
+  const long long p1 = (p0 + pos_per_block < P) ? p0 + pos_per_block : P;
+  if (pl < lanes_p) {
+    for (long long p = p0 + pl; p < p1; p += lanes_p) {
+      const T* src = x + ((size_t)b * P + p) * C + cv * VW;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        const float v = DT<T>::ld(src + e);
+        s[e] += v;
+        q[e] += v * v;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const int g = (cv * VW + e) / cg;
+      atomicAdd(&sm[g][0], s[e]);
+      atomicAdd(&sm[g][1], q[e]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) atomicAdd(&stats[((size_t)b * 32 + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], (double)sm[threadIdx.x >> 1][threadIdx.x & 1]);
+}
+
+template <typename T, int VW>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const double* __restrict__ stats, long long P,
+                                                       int C, float eps, int do_swish) {
+  const int b = blockIdx.y;
+  const long long nvec = P * (C / VW);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const int cv = (int)(i % (C / VW));
+  const int cg = C / 32;
+  const double cnt = (double)P * cg;
+  const T* src = x + (size_t)b * P * C + i * VW;
+  T* dst = y + (size_t)b * P * C + i * VW;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) {
+    const int c = cv * VW + e;
+    const int g = c / cg;
+    const double mean = stats[((size_t)b * 32 + g) * 2] / cnt;
+    double var = stats[((size_t)b * 32 + g) * 2 + 1] / cnt - mean * mean;
+    var = var < 0 ? 0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float v = (DT<T>::ld(src + e) - (float)mean) * rstd * gamma[c] + beta[c];
+    if (do_swish) v = swish_f(v);
+    DT<T>::st(dst + e, v);
+  }
+}
+
+template <typename T>
+int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
+               bool swish, hipStream_t st) {
+  if (C % 32 != 0) {
+    set_error("group_norm: C=%d not divisible by 32 groups", C);
+    return VLG_ERR_BAD_SHAPE;
+  }
+  hipError_t e = hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * sizeof(double), st);
+  if (e != hipSuccess) {
+    set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+    return VLG_ERR_HIP;
+  }
+  const int ppb = 512;
+  dim3 g1((unsigned)cdiv64(P, ppb), B);
+  if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
+    gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, stats, P, C, ppb);
+    dim3 g2((unsigned)cdiv64(P * (C / 8), 256), B);
+    gn_apply_kernel<T, 8><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
+  } else if (C <= 256 && 256 % C == 0) {
+    gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, stats, P, C, ppb);
+    dim3 g2((unsigned)cdiv64(P * C, 256), B);
+    gn_apply_kernel<T, 1><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
+  } else {
+    set_error("group_norm: unsupported channel count %d", C);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  return VLG_OK;
+}
+template int group_norm<float>(const float*, float*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t);
+template int group_norm<bf16>(const bf16*, bf16*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// spatial single-head attention: one wave per query row, online softmax over the frame's HW keys
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int EPL>
+__global__ __launch_bounds__(256) void spatial_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                           T* __restrict__ out, long long nq, int HW, int C, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long qi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const long long f = qi / HW;
+  float qf[EPL], acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    qf[e] = DT<T>::ld(q + qi * C + lane * EPL + e);
+    acc[e] = 0.f;
+  }
+  float mx = -INFINITY, l = 0.f;
+  const T* kb = k + f * HW * (size_t)C + lane * EPL;
+  const T* vb = v + f * HW * (size_t)C + lane * EPL;
+  for (int j = 0; j < HW; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) d = fmaf(qf[e], DT<T>::ld(kb + (size_t)j * C + e), d);
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    d *= scale;
+    const float mn = fmaxf(mx, d);
+    const float a = __expf(mx - mn), pj = __expf(d - mn);
+    l = l * a + pj;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pj * DT<T>::ld(vb + (size_t)j * C + e);
+    mx = mn;
+  }
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) DT<T>::st(out + qi * C + lane * EPL + e, acc[e] / l);
+}
+
+template <typename T>
+int spatial_attention(const T* q, const T* k, const T* v, T* out, int NF, int HW, int C, hipStream_t st) {
+  const long long nq = (long long)NF * HW;
+  const float scale = 1.0f / sqrtf((float)C);   // int(c) ** (-0.5)
+  dim3 grid((unsigned)cdiv64(nq, 4));
+  if (C == 512)
+    spatial_attn_kernel<T, 8><<<grid, 256, 0, st>>>(q, k, v, out, nq, HW, C, scale);
+  else if (C == 256)
+    spatial_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, v, out, nq, HW, C, scale);
+  else if (C == 128)
+    spatial_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, v, out, nq, HW, C, scale);
+  else if (C == 64)
+    spatial_attn_kernel<T, 1><<<grid, 256, 0, st>>>(q, k, v, out, nq, HW, C, scale);
+  else {
+    set_error("spatial_attention: unsupported channel count %d", C);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  return VLG_OK;
+}
+template int spatial_attention<float>(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
+template int spatial_attention<bf16>(const bf16*, const bf16*, const bf16*, bf16*, int, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout glue
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void q12_permute_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, long long HW, int C,
+                                                          int inverse, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  long long r = i / C;
+  const long long hw = r % HW;
+  r /= HW;
+  const int t = (int)(r % Tn);
+  const long long b = r / Tn;
+  int ts, cs;
+  if (!inverse) {  // y[b][t'][hw][c'] = x[b][(t'C+c') % T][hw][(t'C+c') / T]
+    const long long j = (long long)t * C + c;
+    ts = (int)(j % Tn);
+    cs = (int)(j / Tn);
+  } else {         // y[b][t][hw][c] = x[b][(cT+t) / C][hw][(cT+t) % C]
+    const long long j = (long long)c * Tn + t;
+    ts = (int)(j / C);
+    cs = (int)(j % C);
+  }
+  y[i] = x[((b * Tn + ts) * HW + hw) * C + cs];
+}
+template <typename T>
+int q12_permute(const T* x, T* y, int B, int T_, int HW, int C, bool inverse, hipStream_t st) {
+  const long long total = (long long)B * T_ * HW * C;
+  q12_permute_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, T_, HW, C, inverse ? 1 : 0, total);
+  return VLG_OK;
+}
+template int q12_permute<float>(const float*, float*, int, int, int, int, bool, hipStream_t);
+template int q12_permute<bf16>(const bf16*, bf16*, int, int, int, int, bool, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void time_up_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, long long HWC, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int To = 2 * Tn - 1;
+  const long long e = i % HWC;
+  const long long r = i / HWC;
+  const int to = (int)(r % To);
+  const long long b = r / To;
+  const T* xb = x + b * Tn * HWC + e;
+  if (to == 0) {
+    y[i] = xb[0];
+    return;
+  }
+  const int j = to - 1, nrest = Tn - 1;
+  float src = ((float)j + 0.5f) * 0.5f - 0.5f;           // align_corners=False source coordinate
+  src = src < 0.f ? 0.f : src;
+  const int i0 = (int)src;
+  const int i1 = i0 + 1 < nrest ? i0 + 1 : nrest - 1;
+  const float lam = src - (float)i0;
+  const float a = DT<T>::ld(xb + (size_t)(1 + i0) * HWC), c = DT<T>::ld(xb + (size_t)(1 + i1) * HWC);
+  DT<T>::st(y + i, (1.0f - lam) * a + lam * c);
+}
+template <typename T>
+int time_upsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st) {
+  if (T_ <= 1) {
+    hipError_t e = hipMemcpyAsync(y, x, (size_t)B * HWC * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+      set_error("hipMemcpyAsync: %s", hipGetErrorString(e));
+      return VLG_ERR_HIP;
+    }
+    return VLG_OK;
+  }
+  const long long total = (long long)B * (2 * T_ - 1) * HWC;
+  time_up_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, T_, HWC, total);
+  return VLG_OK;
+}
+template int time_upsample2x<float>(const float*, float*, int, int, long long, hipStream_t);
+template int time_upsample2x<bf16>(const bf16*, bf16*, int, int, long long, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ x, T* __restrict__ y, int C, long long P, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long r = i / C;
+  const long long p = r % P;
+  const long long b = r / P;
+  DT<T>::st(y + i, x[(b * C + c) * P + p]);
+}
+template <typename T>
+int planar_f32_to_cl(const float* x, T* y, int B, int C, long long P, hipStream_t st) {
+  const long long total = (long long)B * C * P;
+  planar_to_cl_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, C, P, total);
+  return VLG_OK;
+}
+template int planar_f32_to_cl<float>(const float*, float*, int, int, long long, hipStream_t);
+template int planar_f32_to_cl<bf16>(const float*, bf16*, int, int, long long, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void relayout_w_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cin, int taps, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  const long long r = i / Cin;
+  const int tap = (int)(r % taps);
+  const long long co = r / taps;
+  DT<T>::st(dst + i, src[(co * Cin + ci) * taps + tap]);
+}
+template <typename T>
+int relayout_conv_weight(const float* src, T* dst, int Cout, int Cin, int taps, hipStream_t st) {
+  const long long total = (long long)Cout * Cin * taps;
+  relayout_w_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(src, dst, Cin, taps, total);
+  return VLG_OK;
+}
+template int relayout_conv_weight<float>(const float*, float*, int, int, int, hipStream_t);
+template int relayout_conv_weight<bf16>(const float*, bf16*, int, int, int, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void codebook_lookup_kernel(const float* __restrict__ E, const int32_t* __restrict__ codes,
+                                                              T* __restrict__ out, long long n, int n_e, int e_dim, int l2norm) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int id = codes[i];
+  id = id < 0 ? 0 : (id >= n_e ? n_e - 1 : id);
+  const float* row = E + (size_t)id * e_dim;
+  float inv = 1.f;
+  if (l2norm) {
+    float ss = 0.f;
+    for (int c = 0; c < e_dim; ++c) ss += row[c] * row[c];
+    inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps
+  }
+  for (int c = 0; c < e_dim; ++c) DT<T>::st(out + i * e_dim + c, row[c] * inv);
+}
+template <typename T>
+int codebook_lookup(const float* E, const int32_t* codes, T* out, long long n, int n_e, int e_dim, bool l2norm, hipStream_t st) {
+  codebook_lookup_kernel<T><<<dim3((unsigned)cdiv64(n, 256)), 256, 0, st>>>(E, codes, out, n, n_e, e_dim, l2norm ? 1 : 0);
+  return VLG_OK;
+}
+template int codebook_lookup<float>(const float*, const int32_t*, float*, long long, int, int, bool, hipStream_t);
+template int codebook_lookup<bf16>(const float*, const int32_t*, bf16*, long long, int, int, bool, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// codebook nearest neighbour: one wave per z row, lanes stride over the codes, wavefront arg-min (first minimum)
+//   l2norm = 1: d = (|z|^2 + |e|^2) - 2 z.e on row-normalised z, e       (vq_model.py:221-232)
+//   l2norm = 0: d = (|z|^2 - 2 z.e) + |e|^2                              (tokenizer_video/vqvae.py:166-168)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmin_kernel(const float* __restrict__ z, long long zs_row, long long zs_c, long long rows_per_batch,
+                                                     long long zs_batch, const float* __restrict__ E, long long n, int n_e, int dim,
+                                                     int l2norm, int32_t* __restrict__ idx) {
+  extern __shared__ float zsm[];  // [4][dim]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wv;
+  float* zr = zsm + (size_t)wv * dim;
+  float zz = 0.f;
+  if (row < n) {
+    const float* zp = z + (row / rows_per_batch) * zs_batch + (row % rows_per_batch) * zs_row;
+    float ss = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+      const float v = zp[(size_t)c * zs_c];
+      zr[c] = v;
+      ss += v * v;
+    }
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    zz = ss;
+    if (l2norm) {
+      const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      __builtin_amdgcn_wave_barrier();
+      float s2 = 0.f;
+      for (int c = lane; c < dim; c += 64) {
+        zr[c] *= inv;
+        s2 += zr[c] * zr[c];
+      }
+      for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+      zz = s2;
+    }
+  }
+  __syncthreads();
+  if (row >= n) return;
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < n_e; j += 64) {
+    const float* e = E + (size_t)j * dim;
+    float ee = 0.f, dot = 0.f;
+    float inv = 1.f;
+    if (l2norm) {
+      float s = 0.f;
+      for (int c = 0; c < dim; ++c) s += e[c] * e[c];
+      inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    }
+    for (int c = 0; c < dim; ++c) {
+      const float ev = e[c] * inv;
+      ee += ev * ev;
+      dot = fmaf(zr[c], ev, dot);
+    }
+    const float d = l2norm ? __fsub_rn(__fadd_rn(zz, ee), __fmul_rn(2.0f, dot)) : __fadd_rn(__fsub_rn(zz, __fmul_rn(2.0f, dot)), ee);
+    if (d < best) {
+      best = d;
+      bi = j;
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob < best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  if (lane == 0) idx[row] = bi;
+}
+
+int codebook_argmin(const float* z, long long zs_row, long long zs_c, long long rows_per_batch, long long zs_batch, const float* E,
+                    long long n, int n_e, int dim, bool l2norm, int32_t* idx, hipStream_t st) {
+  if (dim > 4096) {
+    set_error("codebook_argmin: dim %d too large", dim);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  argmin_kernel<<<dim3((unsigned)cdiv64(n, 4)), 256, (size_t)4 * dim * sizeof(float), st>>>(z, zs_row, zs_c, rows_per_batch, zs_batch, E,
+                                                                                             n, n_e, dim, l2norm ? 1 : 0, idx);
+  return VLG_OK;
+}
+
+}  // namespace vlg

@@ -1,17 +1,422 @@
-// placeholder entry points for the VQ / CausalVideoVAE decoders (replaced by the real implementation)
-#include "common.h"
+// vlg_vq / vlg_vae handles: weight store + forward passes of the VQ-16 image decoder and the CausalVideoVAE decoder.
+//
+// Replaces: VQModel.decode_code / VectorQuantizer (tokenizer/tokenizer_image/vq_model.py:47-55,128-276) and
+// CausalVAEModel.decode (CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py:151-262,394-404).
+// Activations live channels-last [B,T,H,W,C] in the handle dtype; conv weights are re-laid out once at load time to
+// [Cout][taps][Cin]; GroupNorm affine params, biases and the codebook stay fp32.
+#include <memory>
+
+#include "conv_kernels.h"
+
 using namespace vlg;
-#define NOTYET(name) set_error(name ": not implemented in this build"); return VLG_ERR_UNSUPPORTED
-extern "C" {
-int vlg_vq_create(const vlg_vq_config*, vlg_vq_t**) { NOTYET("vlg_vq_create"); }
-int vlg_vq_destroy(vlg_vq_t*) { return VLG_OK; }
-int vlg_vq_load_tensor(vlg_vq_t*, const char*, const void*, const int64_t*, int32_t, int32_t, int32_t, int32_t*) { NOTYET("vlg_vq_load_tensor"); }
-int vlg_vq_decode_code(vlg_vq_t*, const int32_t*, int32_t, int32_t, int32_t, float*, void*) { NOTYET("vlg_vq_decode_code"); }
-int vlg_vq_argmin(vlg_vq_t*, const float*, int32_t, int32_t, int32_t, int32_t*, void*) { NOTYET("vlg_vq_argmin"); }
-int vlg_codebook_argmin(const float*, const float*, int32_t, int32_t, int32_t, int32_t*, void*) { NOTYET("vlg_codebook_argmin"); }
-int vlg_vae_create(const vlg_vae_config*, vlg_vae_t**) { NOTYET("vlg_vae_create"); }
-int vlg_vae_destroy(vlg_vae_t*) { return VLG_OK; }
-int vlg_vae_load_tensor(vlg_vae_t*, const char*, const void*, const int64_t*, int32_t, int32_t, int32_t, int32_t*) { NOTYET("vlg_vae_load_tensor"); }
-int vlg_vae_decode(vlg_vae_t*, const float*, int32_t, int32_t, int32_t, int32_t, float*, void*) { NOTYET("vlg_vae_decode"); }
-int vlg_vae_out_shape(vlg_vae_t*, int32_t, int32_t, int32_t, int32_t*, int32_t*, int32_t*) { NOTYET("vlg_vae_out_shape"); }
+
+namespace {
+
+struct Param {
+  DevBuf buf;
+  std::vector<int64_t> shape;  // conv: {Cout, Cin, kt, kh, kw}; other: source shape
+  bool conv = false;
+};
+
+struct Act {
+  void* p = nullptr;
+  int slot = -1;
+  int B = 0, T = 1, H = 0, W = 0, C = 0;
+  long long P() const { return (long long)T * H * W; }
+  long long numel() const { return (long long)B * P() * C; }
+};
+
+struct Store {
+  int dtype = VLG_BF16;
+  size_t esz = 2;
+  std::map<std::string, Param> params;
+  std::vector<std::unique_ptr<DevBuf>> pool;
+  std::vector<bool> busy;
+  DevBuf stats, staging;
+  hipStream_t st = nullptr;
+
+  bool skip(const std::string& n) const {
+    return n.rfind("encoder.", 0) == 0 || n.rfind("quant_conv", 0) == 0 || n.rfind("loss", 0) == 0 ||
+           n.find("codebook_used") != std::string::npos;
+  }
+
+  int load(const char* name, const void* data, const int64_t* shape, int ndim, int src_dtype, int on_dev, int32_t* consumed) {
+    if (consumed) *consumed = 0;
+    const std::string n(name);
+    if (skip(n)) return VLG_OK;
+    VLG_CHECK(ndim >= 1 && ndim <= 5, VLG_ERR_BAD_SHAPE, "%s: ndim %d", name, ndim);
+    int64_t total = 1;
+    for (int i = 0; i < ndim; ++i) total *= shape[i];
+    VLG_CHECK(total > 0, VLG_ERR_BAD_SHAPE, "%s: empty tensor", name);
+    Param& p = params[n];
+    VLG_TRY(staging.reserve((size_t)total * sizeof(float)));
+    VLG_TRY(upload_convert(staging.p, VLG_F32, data, src_dtype, on_dev, total, nullptr));
+    if (ndim >= 4) {  // conv weight [Cout, Cin, (kt,) kh, kw]
+      const int Cout = (int)shape[0], Cin = (int)shape[1];
+      const int kt = ndim == 5 ? (int)shape[2] : 1, kh = (int)shape[ndim - 2], kw = (int)shape[ndim - 1];
+      p.shape = {Cout, Cin, kt, kh, kw};
+      p.conv = true;
+      VLG_TRY(p.buf.reserve((size_t)total * esz));
+      if (dtype == VLG_BF16)
+        VLG_TRY(relayout_conv_weight<bf16>(staging.as<float>(), p.buf.as<bf16>(), Cout, Cin, kt * kh * kw, nullptr));
+      else
+        VLG_TRY(relayout_conv_weight<float>(staging.as<float>(), p.buf.as<float>(), Cout, Cin, kt * kh * kw, nullptr));
+      VLG_HIP(hipStreamSynchronize(nullptr));
+    } else {
+      p.shape.assign(shape, shape + ndim);
+      p.conv = false;
+      VLG_TRY(p.buf.reserve((size_t)total * sizeof(float)));
+      VLG_HIP(hipMemcpy(p.buf.p, staging.p, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (consumed) *consumed = 1;
+    return VLG_OK;
+  }
+
+  const Param* find(const std::string& n) const {
+    auto it = params.find(n);
+    return it == params.end() ? nullptr : &it->second;
+  }
+  bool has(const std::string& n) const { return params.count(n) != 0; }
+
+  int get(size_t bytes, Act& a) {
+    int best = -1;
+    for (size_t i = 0; i < pool.size(); ++i)
+      if (!busy[i] && pool[i]->bytes >= bytes && (best < 0 || pool[i]->bytes < pool[best]->bytes)) best = (int)i;
+    if (best < 0) {
+      for (size_t i = 0; i < pool.size(); ++i)
+        if (!busy[i] && (best < 0 || pool[i]->bytes > pool[best]->bytes)) best = (int)i;
+      if (best < 0) {
+        pool.emplace_back(new DevBuf());
+        busy.push_back(false);
+        best = (int)pool.size() - 1;
+      } else {
+        VLG_HIP(hipStreamSynchronize(st));  // buffer may still be read by queued kernels before it is re-allocated
+      }
+      VLG_TRY(pool[best]->reserve(bytes));
+    }
+    busy[best] = true;
+    a.p = pool[best]->p;
+    a.slot = best;
+    return VLG_OK;
+  }
+  void put(Act& a) {
+    if (a.slot >= 0) busy[a.slot] = false;
+    a.slot = -1;
+    a.p = nullptr;
+  }
+  void release_all() {
+    for (size_t i = 0; i < busy.size(); ++i) busy[i] = false;
+  }
+};
+
+template <typename T>
+struct Net {
+  Store& s;
+  hipStream_t st;
+  std::string csuf;  // ".conv" for CausalConv3d wrappers, "" for nn.Conv2d
+
+  int conv(const Act& x, const std::string& name, int up, const Act* residual, Act& y, float* planar_out = nullptr) {
+    const Param* w = s.find(name + csuf + ".weight");
+    const Param* b = s.find(name + csuf + ".bias");
+    VLG_CHECK(w && w->conv, VLG_ERR_STATE, "weight %s%s.weight was never loaded", name.c_str(), csuf.c_str());
+    VLG_CHECK(w->shape[1] == x.C, VLG_ERR_BAD_SHAPE, "%s: Cin %lld != activation channels %d", name.c_str(), (long long)w->shape[1], x.C);
+    ConvDesc d;
+    d.B = x.B; d.Ti = x.T; d.Hi = x.H; d.Wi = x.W; d.Cin = x.C;
+    d.To = x.T; d.Ho = x.H << up; d.Wo = x.W << up; d.Cout = (int)w->shape[0];
+    d.kt = (int)w->shape[2]; d.kh = (int)w->shape[3]; d.kw = (int)w->shape[4];
+    d.up = up;
+    y.B = d.B; y.T = d.To; y.H = d.Ho; y.W = d.Wo; y.C = d.Cout;
+    if (residual) VLG_CHECK(residual->numel() == y.numel(), VLG_ERR_BAD_SHAPE, "%s: residual shape mismatch", name.c_str());
+    if (!planar_out) VLG_TRY(s.get((size_t)y.numel() * sizeof(T), y));
+    return conv_forward<T>(d, (const T*)x.p, w->buf.as<T>(), b ? b->buf.as<float>() : nullptr, residual ? (const T*)residual->p : nullptr,
+                           planar_out ? nullptr : (T*)y.p, planar_out, st);
+  }
+
+  int gn(const Act& x, const std::string& name, bool swish, Act& y) {
+    const Param* g = s.find(name + ".weight");
+    const Param* b = s.find(name + ".bias");
+    VLG_CHECK(g && b, VLG_ERR_STATE, "GroupNorm %s was never loaded", name.c_str());
+    VLG_CHECK(g->shape[0] == x.C, VLG_ERR_BAD_SHAPE, "%s: %lld channels vs activation %d", name.c_str(), (long long)g->shape[0], x.C);
+    y = x;
+    y.slot = -1;
+    VLG_TRY(s.get((size_t)x.numel() * sizeof(T), y));
+    VLG_TRY(s.stats.reserve((size_t)x.B * 64 * sizeof(double)));
+    return group_norm<T>((const T*)x.p, (T*)y.p, g->buf.as<float>(), b->buf.as<float>(), s.stats.as<double>(), x.B, x.P(), x.C, 1e-6f,
+                         swish, st);
+  }
+
+  // ResnetBlock (vq_model.py:299-314) / ResnetBlock3D (resnet_block.py:158-172); consumes x
+  int resblock(Act& x, const std::string& p, Act& out) {
+    Act h, h2, h3, xs;
+    VLG_TRY(gn(x, p + ".norm1", true, h));
+    VLG_TRY(conv(h, p + ".conv1", 0, nullptr, h2));
+    s.put(h);
+    VLG_TRY(gn(h2, p + ".norm2", true, h3));
+    s.put(h2);
+    const bool shortcut = s.has(p + ".nin_shortcut" + csuf + ".weight");
+    if (shortcut) {
+      VLG_TRY(conv(x, p + ".nin_shortcut", 0, nullptr, xs));
+      s.put(x);
+    } else {
+      xs = x;
+      x.slot = -1;
+    }
+    VLG_TRY(conv(h3, p + ".conv2", 0, &xs, out));
+    s.put(h3);
+    s.put(xs);
+    return VLG_OK;
+  }
+
+  // AttnBlock (vq_model.py:327-351) / AttnBlock3D incl. the Q12 reinterpretation (attention.py:52-76); consumes x
+  int attn(Act& x, const std::string& p, bool q12, Act& out) {
+    Act hn, q, k, v, o;
+    VLG_TRY(gn(x, p + ".norm", false, hn));
+    VLG_TRY(conv(hn, p + ".q", 0, nullptr, q));
+    VLG_TRY(conv(hn, p + ".k", 0, nullptr, k));
+    VLG_TRY(conv(hn, p + ".v", 0, nullptr, v));
+    s.put(hn);
+    const int HW = x.H * x.W;
+    if (q12 && x.T > 1) {
+      for (Act* a : {&q, &k, &v}) {
+        Act tmp = *a;
+        tmp.slot = -1;
+        VLG_TRY(s.get((size_t)a->numel() * sizeof(T), tmp));
+        VLG_TRY(q12_permute<T>((const T*)a->p, (T*)tmp.p, x.B, x.T, HW, x.C, false, st));
+        s.put(*a);
+        *a = tmp;
+      }
+    }
+    o = q;
+    o.slot = -1;
+    VLG_TRY(s.get((size_t)q.numel() * sizeof(T), o));
+    VLG_TRY(spatial_attention<T>((const T*)q.p, (const T*)k.p, (const T*)v.p, (T*)o.p, x.B * x.T, HW, x.C, st));
+    s.put(q);
+    s.put(k);
+    s.put(v);
+    if (q12 && x.T > 1) {
+      Act tmp = o;
+      tmp.slot = -1;
+      VLG_TRY(s.get((size_t)o.numel() * sizeof(T), tmp));
+      VLG_TRY(q12_permute<T>((const T*)o.p, (T*)tmp.p, x.B, x.T, HW, x.C, true, st));
+      s.put(o);
+      o = tmp;
+    }
+    VLG_TRY(conv(o, p + ".proj_out", 0, &x, out));
+    s.put(o);
+    s.put(x);
+    return VLG_OK;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// VQ
+// ---------------------------------------------------------------------------------------------------------------
+struct vlg_vq {
+  vlg_vq_config cfg;
+  Store s;
+};
+
+extern "C" int vlg_vq_create(const vlg_vq_config* cfg, vlg_vq_t** out) {
+  VLG_CHECK(cfg && out, VLG_ERR_BAD_ARG, "vlg_vq_create: null argument");
+  VLG_CHECK(cfg->dtype == VLG_F32 || cfg->dtype == VLG_BF16, VLG_ERR_UNSUPPORTED, "vlg_vq_create: dtype %d", cfg->dtype);
+  VLG_CHECK(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->codebook_size > 0 && cfg->codebook_embed_dim > 0, VLG_ERR_BAD_ARG,
+            "vlg_vq_create: bad config");
+  std::unique_ptr<vlg_vq> h(new vlg_vq());
+  h->cfg = *cfg;
+  h->s.dtype = cfg->dtype;
+  h->s.esz = dtype_size(cfg->dtype);
+  *out = h.release();
+  return VLG_OK;
+}
+extern "C" int vlg_vq_destroy(vlg_vq_t* h) {
+  if (h) {
+    (void)hipDeviceSynchronize();
+    delete h;
+  }
+  return VLG_OK;
+}
+extern "C" int vlg_vq_load_tensor(vlg_vq_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t src_dtype,
+                                  int32_t on_dev, int32_t* consumed) {
+  VLG_CHECK(h && name && data && shape, VLG_ERR_BAD_ARG, "vlg_vq_load_tensor: null argument");
+  if (!strcmp(name, "quantize.embedding.weight"))
+    VLG_CHECK(ndim == 2 && shape[0] == h->cfg.codebook_size && shape[1] == h->cfg.codebook_embed_dim, VLG_ERR_BAD_SHAPE,
+              "size mismatch for quantize.embedding.weight");
+  return h->s.load(name, data, shape, ndim, src_dtype, on_dev, consumed);
+}
+
+template <typename T>
+static int vq_decode_impl(vlg_vq* h, const int32_t* codes, int B, int gh, int gw, float* out, hipStream_t st) {
+  Store& s = h->s;
+  s.st = st;
+  s.release_all();
+  Net<T> net{s, st, ""};
+  const Param* E = s.find("quantize.embedding.weight");
+  VLG_CHECK(E, VLG_ERR_STATE, "quantize.embedding.weight was never loaded");
+  Act z;
+  z.B = B; z.T = 1; z.H = gh; z.W = gw; z.C = h->cfg.codebook_embed_dim;
+  VLG_TRY(s.get((size_t)z.numel() * sizeof(T), z));
+  VLG_TRY(codebook_lookup<T>(E->buf.as<float>(), codes, (T*)z.p, (long long)B * gh * gw, h->cfg.codebook_size, z.C, h->cfg.l2_norm != 0, st));
+  Act a, b;
+  VLG_TRY(net.conv(z, "post_quant_conv", 0, nullptr, a));   // vq_model.py:48
+  s.put(z);
+  VLG_TRY(net.conv(a, "decoder.conv_in", 0, nullptr, b));    // :175
+  s.put(a);
+  VLG_TRY(net.resblock(b, "decoder.mid.0", a));
+  VLG_TRY(net.attn(a, "decoder.mid.1", false, b));
+  VLG_TRY(net.resblock(b, "decoder.mid.2", a));
+  const int nres = h->cfg.n_mult;
+  for (int li = 0; li < nres; ++li) {                         // :182-188 (conv_blocks are stored top level first)
+    for (int j = 0; j <= h->cfg.num_res_blocks; ++j) {
+      const std::string p = "decoder.conv_blocks." + std::to_string(li);
+      VLG_TRY(net.resblock(a, p + ".res." + std::to_string(j), b));
+      if (li == 0) {
+        VLG_TRY(net.attn(b, p + ".attn." + std::to_string(j), false, a));
+      } else {
+        a = b;
+        b.slot = -1;
+      }
+    }
+    if (li != nres - 1) {
+      VLG_TRY(net.conv(a, "decoder.conv_blocks." + std::to_string(li) + ".upsample.conv", 1, nullptr, b));  // nearest 2x + conv (:375-377)
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+  }
+  VLG_TRY(net.gn(a, "decoder.norm_out", true, b));            // :191-192
+  s.put(a);
+  Act y;
+  VLG_TRY(net.conv(b, "decoder.conv_out", 0, nullptr, y, out));
+  s.put(b);
+  return VLG_OK;
+}
+
+extern "C" int vlg_vq_decode_code(vlg_vq_t* h, const int32_t* d_codes, int32_t B, int32_t gh, int32_t gw, float* d_out, void* stream) {
+  VLG_CHECK(h && d_codes && d_out && B > 0 && gh > 0 && gw > 0, VLG_ERR_BAD_ARG, "vlg_vq_decode_code: bad argument");
+  if (h->s.dtype == VLG_BF16) return vq_decode_impl<bf16>(h, d_codes, B, gh, gw, d_out, (hipStream_t)stream);
+  return vq_decode_impl<float>(h, d_codes, B, gh, gw, d_out, (hipStream_t)stream);
+}
+
+extern "C" int vlg_vq_argmin(vlg_vq_t* h, const float* d_z, int32_t B, int32_t Hh, int32_t Ww, int32_t* d_idx, void* stream) {
+  VLG_CHECK(h && d_z && d_idx && B > 0 && Hh > 0 && Ww > 0, VLG_ERR_BAD_ARG, "vlg_vq_argmin: bad argument");
+  const Param* E = h->s.find("quantize.embedding.weight");
+  VLG_CHECK(E, VLG_ERR_STATE, "quantize.embedding.weight was never loaded");
+  const int C = h->cfg.codebook_embed_dim;
+  const long long hw = (long long)Hh * Ww;
+  // z is NCHW: row (b, pos) element c at b*C*hw + c*hw + pos   (the 'b c h w -> b h w c' of vq_model.py:217)
+  return codebook_argmin(d_z, 1, hw, hw, (long long)C * hw, E->buf.as<float>(), (long long)B * hw, h->cfg.codebook_size, C,
+                         h->cfg.l2_norm != 0, d_idx, (hipStream_t)stream);
+}
+
+extern "C" int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim, int32_t* d_idx,
+                                   void* stream) {
+  VLG_CHECK(d_z && d_codebook && d_idx && n > 0 && n_codes > 0 && dim > 0, VLG_ERR_BAD_ARG, "vlg_codebook_argmin: bad argument");
+  return codebook_argmin(d_z, dim, 1, n, 0, d_codebook, n, n_codes, dim, false, d_idx, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CausalVideoVAE
+// ---------------------------------------------------------------------------------------------------------------
+struct vlg_vae {
+  vlg_vae_config cfg;
+  Store s;
+};
+
+extern "C" int vlg_vae_create(const vlg_vae_config* cfg, vlg_vae_t** out) {
+  VLG_CHECK(cfg && out, VLG_ERR_BAD_ARG, "vlg_vae_create: null argument");
+  VLG_CHECK(cfg->dtype == VLG_F32 || cfg->dtype == VLG_BF16, VLG_ERR_UNSUPPORTED, "vlg_vae_create: dtype %d", cfg->dtype);
+  VLG_CHECK(cfg->n_mult >= 1 && cfg->n_mult <= 8 && cfg->embed_dim > 0 && cfg->z_channels > 0, VLG_ERR_BAD_ARG, "vlg_vae_create: bad config");
+  std::unique_ptr<vlg_vae> h(new vlg_vae());
+  h->cfg = *cfg;
+  h->s.dtype = cfg->dtype;
+  h->s.esz = dtype_size(cfg->dtype);
+  *out = h.release();
+  return VLG_OK;
+}
+extern "C" int vlg_vae_destroy(vlg_vae_t* h) {
+  if (h) {
+    (void)hipDeviceSynchronize();
+    delete h;
+  }
+  return VLG_OK;
+}
+extern "C" int vlg_vae_load_tensor(vlg_vae_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t src_dtype,
+                                   int32_t on_dev, int32_t* consumed) {
+  VLG_CHECK(h && name && data && shape, VLG_ERR_BAD_ARG, "vlg_vae_load_tensor: null argument");
+  return h->s.load(name, data, shape, ndim, src_dtype, on_dev, consumed);
+}
+
+extern "C" int vlg_vae_out_shape(vlg_vae_t* h, int32_t t, int32_t hh, int32_t ww, int32_t* T, int32_t* H, int32_t* W) {
+  VLG_CHECK(h && T && H && W, VLG_ERR_BAD_ARG, "vlg_vae_out_shape: null argument");
+  int tt = t, y = hh, x = ww;
+  for (int i = h->cfg.n_mult - 1; i >= 0; --i) {
+    if (h->cfg.spatial_upsample[i]) {
+      y *= 2;
+      x *= 2;
+    }
+    if (h->cfg.temporal_upsample[i] && tt > 1) tt = 2 * tt - 1;
+  }
+  *T = tt;
+  *H = y;
+  *W = x;
+  return VLG_OK;
+}
+
+template <typename T>
+static int vae_decode_impl(vlg_vae* h, const float* z, int B, int t, int hh, int ww, float* out, hipStream_t st) {
+  Store& s = h->s;
+  s.st = st;
+  s.release_all();
+  Net<T> net{s, st, ".conv"};
+  Act a, b;
+  a.B = B; a.T = t; a.H = hh; a.W = ww; a.C = h->cfg.embed_dim;
+  VLG_TRY(s.get((size_t)a.numel() * sizeof(T), a));
+  VLG_TRY(planar_f32_to_cl<T>(z, (T*)a.p, B, a.C, a.P(), st));
+  VLG_TRY(net.conv(a, "post_quant_conv", 0, nullptr, b));     // modeling_causalvae.py:401-402
+  s.put(a);
+  VLG_TRY(net.conv(b, "decoder.conv_in", 0, nullptr, a));      // :244
+  s.put(b);
+  VLG_TRY(net.resblock(a, "decoder.mid.block_1", b));
+  VLG_TRY(net.attn(b, "decoder.mid.attn_1", true, a));
+  VLG_TRY(net.resblock(a, "decoder.mid.block_2", b));
+  a = b;
+  b.slot = -1;
+  for (int lvl = h->cfg.n_mult - 1; lvl >= 0; --lvl) {         // :249-257
+    const std::string p = "decoder.up." + std::to_string(lvl);
+    for (int j = 0; j <= h->cfg.num_res_blocks; ++j) {
+      VLG_TRY(net.resblock(a, p + ".block." + std::to_string(j), b));
+      a = b;
+      b.slot = -1;
+    }
+    if (h->cfg.spatial_upsample[lvl]) {
+      VLG_TRY(net.conv(a, p + ".upsample.conv", 1, nullptr, b)); // SpatialUpsample2x: nearest 2x + (1,3,3) causal conv
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+    if (h->cfg.temporal_upsample[lvl] && a.T > 1) {
+      b = a;
+      b.slot = -1;
+      b.T = 2 * a.T - 1;
+      VLG_TRY(s.get((size_t)b.numel() * sizeof(T), b));
+      VLG_TRY(time_upsample2x<T>((const T*)a.p, (T*)b.p, a.B, a.T, (long long)a.H * a.W * a.C, st));
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+  }
+  VLG_TRY(net.gn(a, "decoder.norm_out", true, b));
+  s.put(a);
+  Act y;
+  VLG_TRY(net.conv(b, "decoder.conv_out", 0, nullptr, y, out));
+  s.put(b);
+  return VLG_OK;
+}
+
+extern "C" int vlg_vae_decode(vlg_vae_t* h, const float* d_z, int32_t B, int32_t t, int32_t hh, int32_t ww, float* d_out, void* stream) {
+  VLG_CHECK(h && d_z && d_out && B > 0 && t > 0 && hh > 0 && ww > 0, VLG_ERR_BAD_ARG, "vlg_vae_decode: bad argument");
+  if (h->s.dtype == VLG_BF16) return vae_decode_impl<bf16>(h, d_z, B, t, hh, ww, d_out, (hipStream_t)stream);
+  return vae_decode_impl<float>(h, d_z, B, t, hh, ww, d_out, (hipStream_t)stream);
 }

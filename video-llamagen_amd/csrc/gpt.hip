@@ -37,12 +37,17 @@ struct vlg_gpt {
   hipStream_t s_int = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   bool use_graph = true;
+  bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
+  std::vector<hipEvent_t> attn_ev;   // 2 per decode step
+  double attn_ms_sum = 0, attn_bytes_sum = 0;
+  long long attn_launches = 0;
   double bytes_w = 0, bytes_kv = 0, bytes_other = 0;
 
   ~vlg_gpt() {
     if (s_int) (void)hipStreamDestroy(s_int);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
+    for (auto e : attn_ev) (void)hipEventDestroy(e);
   }
   const void* W(const std::string& n) const { return w.at(n).buf.p; }
 };
@@ -207,8 +212,20 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->use_graph = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "time_attn")) {
+    h->time_attn = value != 0;
+    return VLG_OK;
+  }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
+}
+
+extern "C" int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches) {
+  VLG_CHECK(h, VLG_ERR_BAD_ARG, "null handle");
+  if (ms_sum) *ms_sum = h->attn_ms_sum;
+  if (bytes_sum) *bytes_sum = h->attn_bytes_sum;
+  if (launches) *launches = h->attn_launches;
+  return VLG_OK;
 }
 
 extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* kb, double* ob) {
@@ -227,6 +244,7 @@ struct Runner {
   hipStream_t st;
   int B, Bp, N, S;
   const float* mask;  // device [B, Tc] or null
+  int ev_slot = -1;   // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
   StepState* state() { return h->state.as<StepState>(); }
   template <typename U>
   const U* W(const std::string& n) {
@@ -254,8 +272,13 @@ struct Runner {
       T* vc = h->vcache.as<T>() + lstride * l;
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
       VLG_TRY(qkv_rope_scatter<T>(ws, sp, h->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st));
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (l == 0 && ev_slot >= 0) {
+        e0 = h->attn_ev[2 * ev_slot];
+        e1 = h->attn_ev[2 * ev_slot + 1];
+      }
       VLG_TRY(attn_rows<T>(h->q.as<T>(), kc, vc, h->ao.as<T>(), h->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st));
+                           h->Tc, st, e0, e1));
       VLG_TRY(gemm_slabs<T>(h->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st));
@@ -379,7 +402,28 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   const int steps = N - 1;
   if (steps > 0) {
-    if (h->use_graph) {
+    if (h->time_attn) {
+      while ((int)h->attn_ev.size() < 2 * steps) {
+        hipEvent_t ev;
+        VLG_HIP(hipEventCreate(&ev));
+        h->attn_ev.push_back(ev);
+      }
+      for (int i = 0; i < steps; ++i) {
+        r.ev_slot = i;
+        VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+      }
+      r.ev_slot = -1;
+      VLG_HIP(hipStreamSynchronize(st));
+      h->attn_ms_sum = 0;
+      h->attn_bytes_sum = 0;
+      for (int i = 0; i < steps; ++i) {
+        float ms = 0.f;
+        VLG_HIP(hipEventElapsedTime(&ms, h->attn_ev[2 * i], h->attn_ev[2 * i + 1]));
+        h->attn_ms_sum += ms;
+        h->attn_bytes_sum += 2.0 * Bp * D * (double)(Tc + i + 1) * e;  // K and V rows 0..p of one layer
+      }
+      h->attn_launches = steps;
+    } else if (h->use_graph) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));

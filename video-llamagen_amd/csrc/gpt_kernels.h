@@ -44,7 +44,7 @@ int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache,
 template <typename T>
 int attn_rows(const T* qbuf, const T* kcache, const T* vcache, T* out, float* partial_ws, const StepState* state,
               int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
-              hipStream_t st);
+              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);  // ev0/ev1 bracket the split-KV kernel
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------

@@ -124,31 +124,31 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x,
     xrow[mt] = x + (size_t)row * K + q * Q;
   }
 
-  u32x4_t a0[MT][4], b0[4], a1[MT][4], b1[4];
-  auto load = [&](int kb, u32x4_t(&a)[MT][4], u32x4_t(&b)[4]) {
-    const u32x4_t* pw = reinterpret_cast<const u32x4_t*>(wrow + (size_t)kb * KBLK);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = __builtin_nontemporal_load(pw + s);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[mt][s] = px[s];
-    }
-  };
-
+  // Every K block this wave owns is requested before the first MFMA: a decode GEMM is ~40-70 KB of weights per
+  // CU in total, so the whole kernel is ONE round trip to HBM when all loads are in flight at once.
+  constexpr int NB = (MT >= 4) ? 2 : 4;
+  u32x4_t a[NB][MT][4], b[NB][4];
   const int stride = 4 * splits;
-  int kb = split * 4 + wave;
-  if (kb < nkb) load(kb, a0, b0);
-  while (kb < nkb) {
-    const int kb1 = kb + stride;
-    if (kb1 < nkb) load(kb1, a1, b1);
-    mfma_block<T, MT>(a0, b0, acc);
-    if (kb1 >= nkb) break;
-    const int kb2 = kb1 + stride;
-    if (kb2 < nkb) load(kb2, a0, b0);
-    mfma_block<T, MT>(a1, b1, acc);
-    kb = kb2;
+  for (int kb0 = split * 4 + wave; kb0 < nkb; kb0 += NB * stride) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kb = kb0 + i * stride;
+      if (kb < nkb) {
+        const u32x4_t* pw = reinterpret_cast<const u32x4_t*>(wrow + (size_t)kb * KBLK);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) b[i][s2] = __builtin_nontemporal_load(pw + s2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (kb0 + i * stride < nkb) mfma_block<T, MT>(a[i], b[i], acc);
+    }
   }
 
   // cross-wave reduction through LDS, then one fp32 slab row segment (64 B) per (row, n-tile)
@@ -200,7 +200,7 @@ static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& 
   if (naive) return;
   const int nkb = K / kblk;
   const int ntiles = N / 16;
-  splits = 768 / (ntiles * mchunks);
+  splits = 1024 / (ntiles * mchunks);
   if (splits > nkb / 4) splits = nkb / 4;
   if (splits > gemm_max_splits()) splits = gemm_max_splits();
   if (splits < 1) splits = 1;
@@ -271,19 +271,39 @@ template <typename T>
 __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ ws, int splits,
                                                                       T* __restrict__ h, const T* __restrict__ w,
                                                                       T* __restrict__ hn, int M, int D, float eps) {
+  constexpr int NE = 8;  // elements per thread per sweep (D <= 2048 in one sweep)
   __shared__ float red[4];
   const int m = blockIdx.x;
   T* hr = h + (size_t)m * D;
   float ss = 0.f;
-  for (int i = threadIdx.x; i < D; i += 256) {
-    float v = DT<T>::ld(hr + i);
-    if (ws) {
-      float s = ws[(size_t)m * D + i];
-      for (int k = 1; k < splits; ++k) s += ws[((size_t)k * M + m) * D + i];
-      v = DT<T>::rt(v + DT<T>::rt(s));
-      DT<T>::st(hr + i, v);
+  for (int base = 0; base < D; base += 256 * NE) {
+    float v[NE], s[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = base + e * 256 + threadIdx.x;
+      v[e] = i < D ? DT<T>::ld(hr + i) : 0.f;
+      s[e] = 0.f;
     }
-    ss += v * v;
+    if (ws) {
+      for (int k = 0; k < splits; ++k) {
+        const float* row = ws + ((size_t)k * M + m) * D;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int i = base + e * 256 + threadIdx.x;
+          if (i < D) s[e] += row[i];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int i = base + e * 256 + threadIdx.x;
+        if (i < D) {
+          v[e] = DT<T>::rt(v[e] + DT<T>::rt(s[e]));
+          DT<T>::st(hr + i, v[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) ss += v[e] * v[e];
   }
   ss = block_sum_256(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)D + eps);
@@ -534,7 +554,7 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
-                       int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st) {
+                       int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const int M = Bp * Tq;
   int nsplit = 2048 / (M * H);
   const int by_len = (max_pos + 1 + 63) / 64;
@@ -542,16 +562,18 @@ static int attn_launch(const T* qbuf, const T* kc, const T* vc, T* out, float* w
   if (nsplit > 16) nsplit = 16;
   if (nsplit < 1) nsplit = 1;
   const float scale = 1.0f / sqrtf((float)HD);
+  if (ev0) (void)hipEventRecord(ev0, st);
   attn_partial_kernel<T, HD, VEC, LPR><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale);
+  if (ev1) (void)hipEventRecord(ev1, st);
   if (nsplit > 1) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
   return VLG_OK;
 }
 
 template <typename T>
 int attn_rows(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
-              int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st) {
+              int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -569,8 +591,8 @@ int attn_rows(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const 
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, const float*, const float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t);
-template int attn_rows<bf16>(const bf16*, const bf16*, const bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t);
+template int attn_rows<float>(const float*, const float*, const float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t);
+template int attn_rows<bf16>(const bf16*, const bf16*, const bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels

@@ -58,6 +58,7 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         out_ids = torch.empty((B, max_new_tokens), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"graph", C.c_int64(1 if model.use_graph else 0)))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"time_attn", C.c_int64(1 if model.time_attn else 0)))
         L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
                                          C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
                                          L.stream_ptr(dev)))

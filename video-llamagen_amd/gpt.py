@@ -105,6 +105,7 @@ class Transformer:
         self._handle = None
         self._loaded = set()
         self.use_graph = True
+        self.time_attn = False
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
     def eval(self):
@@ -178,6 +179,12 @@ class Transformer:
                 self._handle = None
         except Exception:
             pass
+
+    def attn_timing(self):
+        """(total ms, total algorithmic bytes, launches) of the event-timed attention kernel (time_attn=True)."""
+        ms, by, n = C.c_double(), C.c_double(), C.c_int64()
+        L.check(L.lib().vlg_gpt_attn_timing(self._handle, C.byref(ms), C.byref(by), C.byref(n)))
+        return ms.value, by.value, n.value
 
     def algorithmic_bytes(self):
         w, k, o = C.c_double(), C.c_double(), C.c_double()

@@ -1,0 +1,113 @@
+"""Host mirror of CausalVAEModel's decode side (CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py:265-404).
+
+`VAE_models['VAE-16']` (tokenizer/tokenizer_image/vae_model.py:8) -> object with `.config.embed_dim`, `.enable_tiling()`,
+`.tile_overlap_factor`, `.to(dtype)`, `.load_state_dict`, `.decode(z[B,C,t,h,w]) -> [B,3,T,H,W]`.  Tiling never triggers below
+the reference's own thresholds; above them this build raises instead of silently changing semantics.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib as L
+
+
+class CausalVAEModel:
+    def __init__(self, hidden_size=128, z_channels=4, hidden_size_mult=(1, 2, 4, 4), attn_resolutions=(), dropout=0.0,
+                 resolution=256, double_z=True, embed_dim=4, num_res_blocks=2,
+                 decoder_spatial_upsample=("", "SpatialUpsample2x", "SpatialUpsample2x", "SpatialUpsample2x"),
+                 decoder_temporal_upsample=("", "", "TimeUpsample2x", "TimeUpsample2x"), use_quant_layer=True, **_unused):
+        if attn_resolutions:
+            raise L.VlgError(-3, "attn_resolutions != [] is not used by the reference configuration")
+        if not use_quant_layer:
+            raise L.VlgError(-3, "use_quant_layer=False is not supported")
+        self.config = SimpleNamespace(hidden_size=hidden_size, z_channels=z_channels, hidden_size_mult=tuple(hidden_size_mult),
+                                      embed_dim=embed_dim, num_res_blocks=num_res_blocks, resolution=resolution,
+                                      decoder_spatial_upsample=tuple(decoder_spatial_upsample),
+                                      decoder_temporal_upsample=tuple(decoder_temporal_upsample))
+        self.tile_sample_min_size = 512
+        self.tile_sample_min_size_t = 17
+        self.tile_latent_min_size = int(self.tile_sample_min_size / (2 ** (len(hidden_size_mult) - 1)))   # :326
+        self.tile_latent_min_size_t = int((self.tile_sample_min_size_t - 1) / 4) + 1                      # :328
+        self.tile_overlap_factor = 0.125
+        self.use_tiling = False
+        self._dtype = torch.bfloat16
+        self._device = None
+        self._handle = None
+
+    @classmethod
+    def from_config(cls, cfg: dict):
+        return cls(**cfg)
+
+    def enable_tiling(self, use_tiling: bool = True):
+        self.use_tiling = use_tiling
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        if dtype is not None and dtype != self._dtype:
+            if self._handle is not None:
+                raise L.VlgError(-6, "dtype must be chosen before weights are loaded")
+            L.torch_dtype_code(dtype)
+            self._dtype = dtype
+        if device is not None:
+            self._device = torch.device(device)
+        return self
+
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return
+        if self._device is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        c = self.config
+        cfg = L.VaeConfig(hidden_size=c.hidden_size, z_channels=c.z_channels, embed_dim=c.embed_dim, num_res_blocks=c.num_res_blocks,
+                          n_mult=len(c.hidden_size_mult), dtype=L.torch_dtype_code(self._dtype))
+        for i, m in enumerate(c.hidden_size_mult):
+            cfg.hidden_size_mult[i] = m
+            cfg.spatial_upsample[i] = 1 if c.decoder_spatial_upsample[i] else 0
+            cfg.temporal_upsample[i] = 1 if c.decoder_temporal_upsample[i] else 0
+        h = C.c_void_p()
+        with torch.cuda.device(self._device):
+            L.check(L.lib().vlg_vae_create(C.byref(cfg), C.byref(h)))
+        self._handle = h
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._ensure_handle()
+        skipped = []
+        with torch.cuda.device(self._device):
+            for k, v in state_dict.items():
+                if not L.load_tensor(L.lib().vlg_vae_load_tensor, self._handle, k, v):
+                    skipped.append(k)
+        return [], skipped
+
+    @torch.no_grad()
+    def decode(self, z):
+        """z [B, embed_dim, t, h, w] -> float32 [B, 3, T, H, W] (modeling_causalvae.py:394-404)."""
+        self._ensure_handle()
+        if z.dim() != 5 or z.shape[1] != self.config.embed_dim:
+            raise L.VlgError(-2, "z must be [B, %d, t, h, w], got %s" % (self.config.embed_dim, tuple(z.shape)))
+        B, _, t, hh, ww = [int(s) for s in z.shape]
+        if self.use_tiling and (ww > self.tile_latent_min_size or hh > self.tile_latent_min_size or t > self.tile_latent_min_size_t):
+            raise L.VlgError(-3, "tiled_decode (latent > %dx%d or > %d frames) is not implemented" %
+                             (self.tile_latent_min_size, self.tile_latent_min_size, self.tile_latent_min_size_t))
+        zf = z.to(device=self._device, dtype=torch.float32).contiguous()
+        T, H, W = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(L.lib().vlg_vae_out_shape(self._handle, t, hh, ww, C.byref(T), C.byref(H), C.byref(W)))
+        out = torch.empty((B, 3, T.value, H.value, W.value), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().vlg_vae_decode(self._handle, L.ptr(zf), B, t, hh, ww, L.ptr(out), L.stream_ptr(self._device)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                L.lib().vlg_vae_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+VAE_models = {'VAE-16': CausalVAEModel}
