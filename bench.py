@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--cfg-scale", type=float, default=1.0)
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--vae-chunk", type=int, default=4, help="videos per vae.decode call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -129,15 +130,22 @@ def main():
     gpt = build_gpt(V, a, device)
     cond, mask = synth_cond(B, device, seed=1 + rank)
     vae = None
-    if not a.no_vae and full and hasattr(V, "VAE_models"):
-        vae = V.bench_vae(a, device)
+    if not a.no_vae and full:
+        # CausalVAEModel constructor defaults with embed_dim = vae_embed_dim (the only decoder topology
+        # fully defined in the reference), random-initialised, bf16 as in sample_t2v_1f_diff.py:180
+        vae = V.VAE_models["VAE-16"](embed_dim=a.vae_embed_dim).to(device, torch.bfloat16).init_random_weights(seed=3)
+        vae.enable_tiling()
 
     def step():
         lat = V.generate_t2v(gpt, cond, N, mask, cfg_scale=a.cfg_scale)
         out = lat
         if vae is not None:
             z = lat.view(B, vae_t, a.latent, a.latent, a.vae_embed_dim).permute(0, 4, 1, 2, 3).contiguous()
-            out = vae.decode(z)                          # sample_t2v_1f_diff.py:175-181
+            frames = []
+            for i in range(0, B, a.vae_chunk):           # bounded activation footprint; videos are independent
+                v = vae.decode(z[i:i + a.vae_chunk])     # sample_t2v_1f_diff.py:175-181
+                frames.append(((v.clamp(-1, 1) + 1) * 127.5).to(torch.uint8))   # custom_to_video, :49-58
+            out = torch.cat(frames, 0)
         if world > 1:
             gathered = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=device)
             dist.all_gather_into_tensor(gathered, out.contiguous())

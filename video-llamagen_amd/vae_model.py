@@ -83,6 +83,62 @@ class CausalVAEModel:
                     skipped.append(k)
         return [], skipped
 
+    def decoder_param_shapes(self):
+        """name -> shape of every tensor the decode path needs (state-dict names of modeling_causalvae.py:151-262,369)."""
+        c = self.config
+        out = {}
+
+        def conv(name, cout, cin, k):
+            out[name + ".conv.weight"] = (cout, cin) + tuple(k)
+            out[name + ".conv.bias"] = (cout,)
+
+        def gn(name, ch):
+            out[name + ".weight"] = (ch,)
+            out[name + ".bias"] = (ch,)
+
+        def res(p, cin, cout):
+            gn(p + ".norm1", cin)
+            conv(p + ".conv1", cout, cin, (3, 3, 3))
+            gn(p + ".norm2", cout)
+            conv(p + ".conv2", cout, cout, (3, 3, 3))
+            if cin != cout:
+                conv(p + ".nin_shortcut", cout, cin, (1, 1, 1))
+
+        n = len(c.hidden_size_mult)
+        block_in = c.hidden_size * c.hidden_size_mult[n - 1]
+        conv("post_quant_conv", c.z_channels, c.embed_dim, (1, 1, 1))
+        conv("decoder.conv_in", block_in, c.z_channels, (3, 3, 3))
+        res("decoder.mid.block_1", block_in, block_in)
+        gn("decoder.mid.attn_1.norm", block_in)
+        for nm in ("q", "k", "v", "proj_out"):
+            conv("decoder.mid.attn_1." + nm, block_in, block_in, (1, 1, 1))
+        res("decoder.mid.block_2", block_in, block_in)
+        for lvl in reversed(range(n)):
+            block_out = c.hidden_size * c.hidden_size_mult[lvl]
+            for j in range(c.num_res_blocks + 1):
+                res("decoder.up.%d.block.%d" % (lvl, j), block_in, block_out)
+                block_in = block_out
+            if c.decoder_spatial_upsample[lvl]:
+                conv("decoder.up.%d.upsample.conv" % lvl, block_in, block_in, (1, 3, 3))
+        gn("decoder.norm_out", block_in)
+        conv("decoder.conv_out", 3, block_in, (3, 3, 3))
+        return out
+
+    def init_random_weights(self, seed=0):
+        """Random initialisation on the device (stand-in for the reference constructor's nn.Conv3d / GroupNorm init)."""
+        self._ensure_handle()
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        for name, shape in self.decoder_param_shapes().items():
+            if name.endswith("conv.weight"):
+                fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+                t = torch.randn(shape, generator=g, device=self._device) * (0.7 / fan_in ** 0.5)
+            elif ".norm" in name and name.endswith(".weight"):
+                t = torch.ones(shape, device=self._device)
+            else:
+                t = torch.zeros(shape, device=self._device)
+            self.load_state_dict({name: t})
+        return self
+
     @torch.no_grad()
     def decode(self, z):
         """z [B, embed_dim, t, h, w] -> float32 [B, 3, T, H, W] (modeling_causalvae.py:394-404)."""
