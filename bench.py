@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--vae-chunk", type=int, default=4, help="videos per vae.decode call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="batch lanes inside generate (0 = auto)")
+    ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of HIP-graph replay")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +130,8 @@ def main():
     full = N == vae_t * a.latent ** 2
     B = a.batch
     gpt = build_gpt(V, a, device)
+    gpt.lanes = a.lanes
+    gpt.use_graph = not a.no_graph
     cond, mask = synth_cond(B, device, seed=1 + rank)
     vae = None
     if not a.no_vae and full:

@@ -10,12 +10,23 @@
 //   freqs          fp32 [cls + vae_t*g*g, hd/2, 2]; the first cls rows are zero (Q1).
 //   slabs          fp32 [splits][M][N] split-K partial sums, consumed by the next kernel.
 //   StepState      {pos, step} in device memory, bumped by a 1-thread kernel so the decode step graph is replayable.
+#include <algorithm>
 #include <cmath>
 #include <memory>
 
 #include "gpt_kernels.h"
 
 using namespace vlg;
+
+struct Lane {
+  DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
+  hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr;
+  ~Lane() {
+    if (st) (void)hipStreamDestroy(st);
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
 
 struct vlg_gpt {
   vlg_gpt_config cfg;
@@ -31,12 +42,15 @@ struct vlg_gpt {
   std::map<std::string, Tensor> w;
   DevBuf freqs;
 
-  // per-generate state
-  int Bp_cap = 0, S_cap = 0, M_cap = 0;
-  DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat, maskbuf;
-  hipStream_t s_int = nullptr;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
+  std::vector<std::unique_ptr<Lane>> lanes;
+  int lanes_opt = 0;   // 0 = auto
+  int last_lanes = 1;
+  hipStream_t s_int = nullptr;   // weight uploads
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
   bool use_graph = true;
+  bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
+  bool fuse_qkv = true;              // decode: RoPE + KV append inside the attention kernel
   bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
   std::vector<hipEvent_t> attn_ev;   // 2 per decode step
   double attn_ms_sum = 0, attn_bytes_sum = 0;
@@ -47,6 +61,7 @@ struct vlg_gpt {
     if (s_int) (void)hipStreamDestroy(s_int);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto e : attn_ev) (void)hipEventDestroy(e);
   }
   const void* W(const std::string& n) const { return w.at(n).buf.p; }
@@ -170,7 +185,7 @@ extern "C" int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out) {
   VLG_HIP(hipStreamCreateWithFlags(&h->s_int, hipStreamNonBlocking));
   VLG_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
   VLG_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
-  VLG_TRY(h->state.reserve(sizeof(StepState)));
+  VLG_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   *out = h.release();
   return VLG_OK;
 }
@@ -216,6 +231,19 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->time_attn = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "fuse_swiglu")) {
+    h->fuse_swiglu = value != 0;
+    return VLG_OK;
+  }
+  if (!strcmp(key, "fuse_qkv")) {
+    h->fuse_qkv = value != 0;
+    return VLG_OK;
+  }
+  if (!strcmp(key, "lanes")) {
+    VLG_CHECK(value >= 0 && value <= 4, VLG_ERR_BAD_ARG, "lanes must be 0 (auto) .. 4");
+    h->lanes_opt = (int)value;
+    return VLG_OK;
+  }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
 }
@@ -238,14 +266,19 @@ extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* 
 
 namespace {
 
+// One lane = an independent slice of the batch with its own activations, KV cache, step state and stream.
+// Lanes share the weights.  Two lanes on forked graph branches let one lane's latency-bound kernels (skinny GEMMs,
+// norms, RoPE) run under the other lane's HBM-bound attention.
 template <typename T>
 struct Runner {
   vlg_gpt* h;
+  Lane* ln;
   hipStream_t st;
-  int B, Bp, N, S;
-  const float* mask;  // device [B, Tc] or null
-  int ev_slot = -1;   // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
-  StepState* state() { return h->state.as<StepState>(); }
+  int B, Bp, N, S;     // lane batch, lane rows (2B with CFG), tokens to generate, cache length
+  int b0, Btot;        // first sample of the lane within the call's batch, call batch
+  const float* mask;   // device [B, Tc] (lane slice) or null
+  int ev_slot = -1;    // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
+  StepState* state() { return ln->state.as<StepState>(); }
   template <typename U>
   const U* W(const std::string& n) {
     return reinterpret_cast<const U*>(h->W(n));
@@ -253,37 +286,40 @@ struct Runner {
 
   int linear(const T* x, const std::string& wname, T* out, float* out_f32, int M, int Nn, int K, int act) {
     int sp = 1;
-    VLG_TRY(gemm_slabs<T>(x, W<T>(wname), h->ws.as<float>(), M, Nn, K, &sp, st));
-    return reduce_store<T>(h->ws.as<float>(), sp, out, out_f32, M, Nn, act, st);
+    VLG_TRY(gemm_slabs<T>(x, W<T>(wname), ln->ws.as<float>(), M, Nn, K, &sp, st));
+    return reduce_store<T>(ln->ws.as<float>(), sp, out, out_f32, M, Nn, act, st);
   }
 
   // x [M, D] (rows m = b*Tq + t) -> xn = final-normed hidden
   int layers(int Tq, int max_pos) {
     const int M = Bp * Tq, D = h->D, H = h->H, hd = h->hd, F = h->F;
-    T* x = h->x.as<T>();
-    T* xn = h->xn.as<T>();
-    float* ws = h->ws.as<float>();
+    T* x = ln->x.as<T>();
+    T* xn = ln->xn.as<T>();
+    float* ws = ln->ws.as<float>();
     const size_t lstride = (size_t)Bp * H * S * hd;
     VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, W<T>("layers.0.attention_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
       int sp = 1;
-      T* kc = h->kcache.as<T>() + lstride * l;
-      T* vc = h->vcache.as<T>() + lstride * l;
+      T* kc = ln->kcache.as<T>() + lstride * l;
+      T* vc = ln->vcache.as<T>() + lstride * l;
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
-      VLG_TRY(qkv_rope_scatter<T>(ws, sp, h->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st));
+      const bool fused = (Tq == 1) && h->fuse_qkv;
+      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
-      VLG_TRY(attn_rows<T>(h->q.as<T>(), kc, vc, h->ao.as<T>(), h->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st, e0, e1));
-      VLG_TRY(gemm_slabs<T>(h->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
+      VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
+                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>()));
+      VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
-      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st));
-      VLG_TRY(reduce_silu_mul<T>(ws, sp, h->g.as<T>(), M, F, st));
-      VLG_TRY(gemm_slabs<T>(h->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st));
+      if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
+        VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st));
+        VLG_TRY(reduce_silu_mul<T>(ws, sp, ln->g.as<T>(), M, F, st));
+      }
+      VLG_TRY(gemm_slabs<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st));
       const std::string nxt = (l + 1 < h->L) ? "layers." + std::to_string(l + 1) + ".attention_norm.weight" : std::string("norm.weight");
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(nxt), xn, M, D, h->cfg.norm_eps, st));
     }
@@ -294,15 +330,15 @@ struct Runner {
   int head(const T* hl, const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
     if (h->cfg.head == VLG_HEAD_LOGITS) {
-      VLG_TRY(linear(hl, "output.weight", nullptr, h->logits.as<float>(), Bp, h->V, D, ACT_NONE));
-      return sample_rows(h->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids, h->cur_tok.as<int32_t>(), trace,
-                         nullptr, st);
+      VLG_TRY(linear(hl, "output.weight", nullptr, ln->logits.as<float>(), Bp, h->V, D, ACT_NONE));
+      return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
+                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot);
     }
     if (h->cfg.head == VLG_HEAD_ADAPTER2) {
-      VLG_TRY(linear(hl, "vae_latent_adapter2.fc1.weight", h->t1.as<T>(), nullptr, Bp, D, D, ACT_GELU_TANH));
-      VLG_TRY(linear(h->t1.as<T>(), "vae_latent_adapter2.fc2.weight", h->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
-      return latent_head_finish<T>(h->y.as<T>(), h->cur_lat.as<float>(), out_lat, trace, state(), B, Bp, h->C, N, sp.cfg_scale,
-                                   sp.cfg_interval, st);
+      VLG_TRY(linear(hl, "vae_latent_adapter2.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, D, ACT_GELU_TANH));
+      VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter2.fc2.weight", ln->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
+      return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
+                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
     }
     set_error("hidden (diffusion) head is not implemented yet");
     return VLG_ERR_UNSUPPORTED;
@@ -311,14 +347,14 @@ struct Runner {
   int decode_step(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
     if (h->cfg.model_type == VLG_T2V) {
-      VLG_TRY(latent_to_rows<T>(h->cur_lat.as<float>(), h->latT.as<T>(), B, Bp, h->C, st));
-      VLG_TRY(linear(h->latT.as<T>(), "vae_latent_adapter.fc1.weight", h->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
-      VLG_TRY(linear(h->t1.as<T>(), "vae_latent_adapter.fc2.weight", h->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));
+      VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
+      VLG_TRY(linear(ln->latT.as<T>(), "vae_latent_adapter.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
+      VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter.fc2.weight", ln->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));
     } else {
-      VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), h->cur_tok.as<int32_t>(), h->x.as<T>(), Bp, D, st));
+      VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st));
     }
     VLG_TRY(layers(1, S - 1));
-    VLG_TRY(head(h->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
+    VLG_TRY(head(ln->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
     return advance_state(state(), st);
   }
 
@@ -326,43 +362,32 @@ struct Runner {
     const int D = h->D, Tc = h->Tc;
     VLG_TRY(set_state(state(), 0, 0, st));
     if (h->cfg.model_type == VLG_C2I) {
-      VLG_TRY(gather_rows_i64<T>(W<T>("cls_embedding.embedding_table.weight"), (const int64_t*)d_cond, B, h->cfg.num_classes,
-                                 h->x.as<T>(), Bp, D, st));
+      VLG_TRY(gather_rows_i64<T>(W<T>("cls_embedding.embedding_table.weight"), (const int64_t*)d_cond + b0, B, h->cfg.num_classes,
+                                 ln->x.as<T>(), Bp, D, h->cfg.num_classes + 1, st));
     } else {
       const int M = Bp * Tc;
-      VLG_TRY(build_text_cond<T>((const float*)d_cond, W<T>("cls_embedding.uncond_embedding"), h->condT.as<T>(), B, Bp, Tc, h->cd, st));
-      VLG_TRY(linear(h->condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", h->t1.as<T>(), nullptr, M, D, h->cd, ACT_GELU_TANH));
-      VLG_TRY(linear(h->t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", h->x.as<T>(), nullptr, M, D, D, ACT_NONE));
+      VLG_TRY(build_text_cond<T>((const float*)d_cond + (size_t)b0 * Tc * h->cd, W<T>("cls_embedding.uncond_embedding"), ln->condT.as<T>(),
+                                 B, Bp, Tc, h->cd, st));
+      VLG_TRY(linear(ln->condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", ln->t1.as<T>(), nullptr, M, D, h->cd, ACT_GELU_TANH));
+      VLG_TRY(linear(ln->t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", ln->x.as<T>(), nullptr, M, D, D, ACT_NONE));
     }
     VLG_TRY(layers(Tc, Tc - 1));
-    const T* hl = h->xn.as<T>();
+    const T* hl = ln->xn.as<T>();
     if (Tc > 1) {
-      VLG_TRY(take_last_rows<T>(h->xn.as<T>(), h->hl.as<T>(), Bp, Tc, D, st));
-      hl = h->hl.as<T>();
+      VLG_TRY(take_last_rows<T>(ln->xn.as<T>(), ln->hl.as<T>(), Bp, Tc, D, st));
+      hl = ln->hl.as<T>();
     }
     VLG_TRY(head(hl, sp, noise, out_ids, out_lat, trace));
     return set_state(state(), Tc, 1, st);
   }
 };
 
-template <typename T>
-int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, int N, const vlg_sampling_params& sp,
-                  const float* d_noise, int32_t* out_ids, float* out_lat, float* trace, hipStream_t caller) {
-  const bool cfg_on = sp.cfg_scale > 1.0f;
-  const int Bp = cfg_on ? 2 * B : B;
+int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
   const int Tc = h->Tc, D = h->D, H = h->H, hd = h->hd, F = h->F;
-  const int S = round_up(Tc + N, 8);  // gpt.py:322
-  VLG_CHECK(Tc + N <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table (%d positions after %d cond tokens)", N,
-            h->npos - Tc, Tc);
-  if (cfg_on && h->cfg.model_type != VLG_C2I)
-    VLG_CHECK(Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
-  for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
-
-  // ---- buffers (grow-only) -------------------------------------------------------------------------------
   const int M = Bp * Tc;  // prefill rows
   const size_t e = h->esz;
-  VLG_TRY(h->kcache.reserve((size_t)h->L * Bp * H * S * hd * e));
-  VLG_TRY(h->vcache.reserve((size_t)h->L * Bp * H * S * hd * e));
+  VLG_TRY(ln.kcache.reserve((size_t)h->L * Bp * H * S * hd * e));
+  VLG_TRY(ln.vcache.reserve((size_t)h->L * Bp * H * S * hd * e));
   size_t wsf = 0;
   auto need = [&](int m, int n, int k) { wsf = std::max(wsf, gemm_ws_floats(m, n, k, (int)e)); };
   for (int m : {M, Bp}) {
@@ -375,85 +400,139 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   need(Bp, h->V > 0 ? h->V : D, D);
   need(Bp, D, h->C > 0 ? h->C : D);
   need(Bp, h->C > 0 ? h->C : D, D);
-  VLG_TRY(h->ws.reserve(wsf * sizeof(float)));
-  VLG_TRY(h->attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
-  VLG_TRY(h->x.reserve((size_t)M * D * e));
-  VLG_TRY(h->xn.reserve((size_t)M * D * e));
-  VLG_TRY(h->q.reserve((size_t)M * D * e));
-  VLG_TRY(h->ao.reserve((size_t)M * D * e));
-  VLG_TRY(h->g.reserve((size_t)M * F * e));
-  VLG_TRY(h->t1.reserve((size_t)M * D * e));
-  VLG_TRY(h->hl.reserve((size_t)Bp * D * e));
-  if (h->cd > 0) VLG_TRY(h->condT.reserve((size_t)M * h->cd * e));
+  VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
+  VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
+  VLG_TRY(ln.x.reserve((size_t)M * D * e));
+  VLG_TRY(ln.xn.reserve((size_t)M * D * e));
+  VLG_TRY(ln.q.reserve((size_t)M * D * e));
+  VLG_TRY(ln.ao.reserve((size_t)M * D * e));
+  VLG_TRY(ln.g.reserve((size_t)M * F * e));
+  VLG_TRY(ln.t1.reserve((size_t)M * D * e));
+  VLG_TRY(ln.hl.reserve((size_t)Bp * D * e));
+  if (h->cd > 0) VLG_TRY(ln.condT.reserve((size_t)M * h->cd * e));
   if (h->C > 0) {
-    VLG_TRY(h->latT.reserve((size_t)Bp * h->C * e));
-    VLG_TRY(h->y.reserve((size_t)Bp * h->C * e));
-    VLG_TRY(h->cur_lat.reserve((size_t)B * h->C * sizeof(float)));
+    VLG_TRY(ln.latT.reserve((size_t)Bp * h->C * e));
+    VLG_TRY(ln.y.reserve((size_t)Bp * h->C * e));
+    VLG_TRY(ln.cur_lat.reserve((size_t)B * h->C * sizeof(float)));
   }
-  if (h->V > 0) VLG_TRY(h->logits.reserve((size_t)Bp * h->V * sizeof(float)));
-  VLG_TRY(h->cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
+  if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
+  VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
+  VLG_TRY(ln.state.reserve(sizeof(StepState)));
+  if (!ln.st) VLG_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
+  if (!ln.ev) VLG_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
+  return VLG_OK;
+}
 
-  // ---- run on the internal stream, ordered after/before the caller's stream --------------------------------
-  hipStream_t st = h->s_int;
+template <typename T>
+int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, int N, const vlg_sampling_params& sp,
+                  const float* d_noise, int32_t* out_ids, float* out_lat, float* trace, hipStream_t caller) {
+  const bool cfg_on = sp.cfg_scale > 1.0f;
+  const int Tc = h->Tc, D = h->D, F = h->F;
+  const int S = round_up(Tc + N, 8);  // gpt.py:322
+  VLG_CHECK(Tc + N <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table (%d positions after %d cond tokens)", N,
+            h->npos - Tc, Tc);
+  if (cfg_on && h->cfg.model_type != VLG_C2I)
+    VLG_CHECK(Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
+  for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
+
+  // ---- lanes: contiguous sample ranges, each with its own buffers (grow-only) and stream -------------------
+  int nl = h->lanes_opt;
+  if (nl <= 0) nl = 1;   // auto: measured on MI355X (r01): kernels of two lanes do not overlap enough to pay for streaming the weights twice
+  if (nl > B) nl = B;
+  if (nl > 4) nl = 4;
+  while ((int)h->lanes.size() < nl) h->lanes.emplace_back(new Lane());
+  std::vector<Runner<T>> rs;
+  for (int i = 0; i < nl; ++i) {
+    const int lo = (int)((long long)B * i / nl), hi = (int)((long long)B * (i + 1) / nl);
+    const int Bl = hi - lo, Bpl = cfg_on ? 2 * Bl : Bl;
+    Lane* ln = h->lanes[i].get();
+    VLG_TRY(reserve_lane(h, *ln, Bl, Bpl, S));
+    rs.push_back(Runner<T>{h, ln, ln->st, Bl, Bpl, N, S, lo, B, d_mask ? d_mask + (size_t)lo * Tc : nullptr});
+  }
+  h->last_lanes = nl;
+
+  // ---- fork from the caller's stream ----------------------------------------------------------------------------
   VLG_HIP(hipEventRecord(h->ev_in, caller));
-  VLG_HIP(hipStreamWaitEvent(st, h->ev_in, 0));
-
-  Runner<T> r{h, st, B, Bp, N, S, d_mask};
-  VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
+  for (auto& r : rs) VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
+  for (auto& r : rs) VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
+  hipStream_t s0 = rs[0].st;
   const int steps = N - 1;
   if (steps > 0) {
     if (h->time_attn) {
+      // eager loop on every lane's stream; HIP events (on lane 0's stream) around lane 0 / layer 0's attention kernel
       while ((int)h->attn_ev.size() < 2 * steps) {
         hipEvent_t ev;
         VLG_HIP(hipEventCreate(&ev));
         h->attn_ev.push_back(ev);
       }
       for (int i = 0; i < steps; ++i) {
-        r.ev_slot = i;
-        VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+        rs[0].ev_slot = i;
+        for (auto& r : rs) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
       }
-      r.ev_slot = -1;
-      VLG_HIP(hipStreamSynchronize(st));
+      rs[0].ev_slot = -1;
+      for (auto& r : rs) VLG_HIP(hipStreamSynchronize(r.st));
       h->attn_ms_sum = 0;
       h->attn_bytes_sum = 0;
       for (int i = 0; i < steps; ++i) {
         float ms = 0.f;
         VLG_HIP(hipEventElapsedTime(&ms, h->attn_ev[2 * i], h->attn_ev[2 * i + 1]));
         h->attn_ms_sum += ms;
-        h->attn_bytes_sum += 2.0 * Bp * D * (double)(Tc + i + 1) * e;  // K and V rows 0..p of one layer
+        h->attn_bytes_sum += 2.0 * rs[0].Bp * D * (double)(Tc + i + 1) * h->esz;  // K and V rows 0..p of one layer, lane 0
       }
       h->attn_launches = steps;
     } else if (h->use_graph) {
+      // one graph = one decode step of every lane, lanes on parallel branches (fork/join on lane 0's stream)
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
-      VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = r.decode_step(sp, d_noise, out_ids, out_lat, trace);
-      hipError_t ce = hipStreamEndCapture(st, &graph);
+      for (size_t i = 1; i < rs.size(); ++i) {  // order the other lanes' prefill before the captured region
+        VLG_HIP(hipEventRecord(rs[i].ln->ev, rs[i].st));
+        VLG_HIP(hipStreamWaitEvent(s0, rs[i].ln->ev, 0));
+      }
+      VLG_HIP(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+      int rc = VLG_OK;
+      hipError_t ce = hipSuccess;
+      if (rs.size() > 1) {
+        ce = hipEventRecord(h->ev_fork, s0);
+        for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) ce = hipStreamWaitEvent(rs[i].st, h->ev_fork, 0);
+      }
+      for (size_t i = 0; i < rs.size() && rc == VLG_OK && ce == hipSuccess; ++i) rc = rs[i].decode_step(sp, d_noise, out_ids, out_lat, trace);
+      for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) {
+        ce = hipEventRecord(rs[i].ln->ev, rs[i].st);
+        if (ce == hipSuccess) ce = hipStreamWaitEvent(s0, rs[i].ln->ev, 0);
+      }
+      hipError_t ee = hipStreamEndCapture(s0, &graph);
       if (rc != VLG_OK) {
         if (graph) (void)hipGraphDestroy(graph);
         return rc;
       }
       VLG_HIP(ce);
+      VLG_HIP(ee);
       VLG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       for (int i = 0; i < steps; ++i) {
-        hipError_t le = hipGraphLaunch(exec, st);
+        hipError_t le = hipGraphLaunch(exec, s0);
         if (le != hipSuccess) {
           (void)hipGraphExecDestroy(exec);
           (void)hipGraphDestroy(graph);
           VLG_HIP(le);
         }
       }
-      VLG_HIP(hipStreamSynchronize(st));
+      VLG_HIP(hipStreamSynchronize(s0));
       (void)hipGraphExecDestroy(exec);
       (void)hipGraphDestroy(graph);
     } else {
-      for (int i = 0; i < steps; ++i) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+      for (int i = 0; i < steps; ++i)
+        for (auto& r : rs) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
     }
   }
-  VLG_HIP(hipEventRecord(h->ev_out, st));
-  VLG_HIP(hipStreamWaitEvent(caller, h->ev_out, 0));
+  // ---- join back into the caller's stream ---------------------------------------------------------------------------
+  for (auto& r : rs) {
+    VLG_HIP(hipEventRecord(r.ln->ev, r.st));
+    VLG_HIP(hipStreamWaitEvent(caller, r.ln->ev, 0));
+  }
 
-  // ---- algorithmic bytes of this call ---------------------------------------------------------
+  // ---- algorithmic bytes of this call; weights are streamed once per lane and step ------------------
+  const int Bp = cfg_on ? 2 * B : B;
+  const size_t e = h->esz;
   double P = (double)h->L * (4.0 * D * D + 3.0 * D * F);
   if (h->cfg.head == VLG_HEAD_LOGITS) P += (double)D * h->V;
   if (h->cfg.model_type == VLG_T2V) P += 2.0 * D * D + 2.0 * D * h->C;
@@ -552,10 +631,10 @@ extern "C" int vlg_attn_decode(const void* d_q, const void* d_k, const void* d_v
   const StepState ss{pos, 0};
   VLG_HIP(hipMemcpy(s.state.p, &ss, sizeof(ss), hipMemcpyHostToDevice));
   if (dtype == VLG_BF16)
-    return attn_rows<bf16>((const bf16*)d_q, (const bf16*)d_k, (const bf16*)d_v, (bf16*)d_out, s.aux.as<float>(), s.state.as<StepState>(),
+    return attn_rows<bf16>((const bf16*)d_q, (bf16*)d_k, (bf16*)d_v, (bf16*)d_out, s.aux.as<float>(), s.state.as<StepState>(),
                            Bp, 1, H, hd, S, pos, d_mask, Bmask > 0 ? Bmask : 1, Tc, st);
   if (dtype == VLG_F32)
-    return attn_rows<float>((const float*)d_q, (const float*)d_k, (const float*)d_v, (float*)d_out, s.aux.as<float>(),
+    return attn_rows<float>((const float*)d_q, (float*)d_k, (float*)d_v, (float*)d_out, s.aux.as<float>(),
                             s.state.as<StepState>(), Bp, 1, H, hd, S, pos, d_mask, Bmask > 0 ? Bmask : 1, Tc, st);
   set_error("vlg_attn_decode: dtype %d", dtype);
   return VLG_ERR_UNSUPPORTED;

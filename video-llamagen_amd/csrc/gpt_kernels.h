@@ -17,6 +17,9 @@ enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1 };
 template <typename T>
 int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits, hipStream_t st);
 int gemm_max_splits();
+// fused SwiGLU up-projection: g = rt(rt(silu(rt(x w1^T))) * rt(x w3^T)), w13 = [w1; w3]; false -> use the generic path
+template <typename T>
+bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_t st);
 size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 
 // out[m][n] = rt(act(rt(sum_s slab[s][m][n])));  out_f32 (optional) receives float(rt(sum)) (gpt.py:371)
@@ -41,17 +44,20 @@ int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache,
 // attention of every query row m = b*Tq + t (position p = state->pos + t) over keys 0..p of batch b
 // (gpt.py:230-237 with the mask of generate.py:156-165).  out [M, H*hd].
 // mask: fp32 [Bmask, Tc] or null; batch row b uses mask row b % Bmask.
+// qkv_ws != null (decode, Tq == 1 only): fused mode - q/k/v come from the QKV GEMM slabs [qkv_splits][M][3D], RoPE and the
+// KV-cache append happen inside the attention kernel (qbuf unused, no qkv_rope_scatter launch).
 template <typename T>
-int attn_rows(const T* qbuf, const T* kcache, const T* vcache, T* out, float* partial_ws, const StepState* state,
+int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, const StepState* state,
               int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
-              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);  // ev0/ev1 bracket the split-KV kernel
+              hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,  // ev0/ev1 bracket the split-KV kernel
+              const float* qkv_ws = nullptr, int qkv_splits = 0, const float* freqs = nullptr);
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------
 template <typename T>
-int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, hipStream_t st);   // gpt.py:354
+int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st);   // gpt.py:354
 template <typename T>
-int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, hipStream_t st);  // gpt.py:82 + generate.py:131
+int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, int n_rows, hipStream_t st);  // gpt.py:82 + generate.py:131
 // cond [B,Tc,cd] fp32 (+ uncond [120,cd] for the CFG half) -> T [Bp*Tc, cd]        (generate.py:138-139)
 template <typename T>
 int build_text_cond(const float* cond, const T* uncond, T* out, int B, int Bp, int Tc, int cd, hipStream_t st);
@@ -64,7 +70,7 @@ int latent_to_rows(const float* cur, T* out, int B, int Bp, int C, hipStream_t s
 // head output T [Bp, C] -> CFG combine (generate_video_diff.py:97-105) -> out_lat[b][step] fp32 and cur [B,C]
 template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp,
-                       int C, int N, float cfg_scale, int cfg_interval, hipStream_t st);
+                       int C, int N, float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
 
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
@@ -74,6 +80,8 @@ int set_state(StepState* state, int pos, int step, hipStream_t st);
 // trace[step][b][V] (if trace), probs[b][V] (if probs).  noise: fp32 [N or 1][B][V] indexed by step.
 int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampling_params& sp, const float* noise,
                 const StepState* state, int fixed_step, int N, int32_t* out_ids, int32_t* cur_tok, float* trace,
-                float* probs, hipStream_t st);
+                float* probs, hipStream_t st, int b_off = 0, int B_total = 0);
+// b_off / B_total: the rows are samples b_off.. of a B_total-sample call (batch lanes): noise, trace and the Philox
+// counter are indexed by the global sample id so results do not depend on the lane split.
 
 }  // namespace vlg

@@ -100,63 +100,81 @@ __device__ __forceinline__ void mfma_block(const u32x4_t (&a)[MT][4], const u32x
   }
 }
 
-template <typename T, int MT>
+// DUAL = false: plain GEMM, fp32 partial slabs out.
+// DUAL = true : the n-tile is taken from BOTH halves of a [2F, K] weight (rows n and F + n: w1 and w3 of SwiGLU, gpt.py:161-167);
+//               no K split across workgroups, and the epilogue writes g = rt(rt(silu(rt(a))) * rt(b)) directly - no slab
+//               round trip and no separate SiLU*mul kernel.
+template <typename T, int MT, bool DUAL>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x, const T* __restrict__ w,
-                                                        float* __restrict__ slabs, int M, int N, int K) {
+                                                        float* __restrict__ slabs, T* __restrict__ gout, int M, int N, int K) {
   constexpr int KBLK = GemmT<T>::KBLK;
-  constexpr int Q = KBLK / 4;  // elements per lane per block (64 B)
+  constexpr int NH = DUAL ? 2 : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
   const int split = blockIdx.z, splits = gridDim.z;
   const int nkb = K / KBLK;
 
-  f32x4_t acc[MT];
+  f32x4_t acc[NH][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[hf][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const T* wrow = w + (size_t)(n0 + r) * K + q * Q;
+  // natural k order: load instruction s of a K block reads, for each of the 16 rows, 64 contiguous bytes
+  // (4 lanes x 16 B): lane (r, q) gets elements [s*KBLK/4 + q*KBLK/16, +KBLK/16) - identical for A and B operands.
+  const T* wrow[NH];
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) wrow[hf] = w + (size_t)(n0 + r + (DUAL ? hf * N : 0)) * K;
   const T* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int row = m0 + mt * 16 + r;
     row = row < M ? row : M - 1;
-    xrow[mt] = x + (size_t)row * K + q * Q;
+    xrow[mt] = x + (size_t)row * K;
   }
 
   // Every K block this wave owns is requested before the first MFMA: a decode GEMM is ~40-70 KB of weights per
   // CU in total, so the whole kernel is ONE round trip to HBM when all loads are in flight at once.
-  constexpr int NB = (MT >= 4) ? 2 : 4;
-  u32x4_t a[NB][MT][4], b[NB][4];
+  constexpr int NB = (MT * NH >= 4) ? 2 : 4;
+  u32x4_t a[NB][MT][4], b[NB][NH][4];
   const int stride = 4 * splits;
   for (int kb0 = split * 4 + wave; kb0 < nkb; kb0 += NB * stride) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int kb = kb0 + i * stride;
       if (kb < nkb) {
-        const u32x4_t* pw = reinterpret_cast<const u32x4_t*>(wrow + (size_t)kb * KBLK);
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) b[i][s2] = __builtin_nontemporal_load(pw + s2);
+        for (int hf = 0; hf < NH; ++hf) {
+          const u32x4_t* pw = reinterpret_cast<const u32x4_t*>(wrow[hf] + (size_t)kb * KBLK) + q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) b[i][hf][s2] = __builtin_nontemporal_load(pw + s2 * 4);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK);
+          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK) + q;
 #pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2];
+          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * 4];
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if (kb0 + i * stride < nkb) mfma_block<T, MT>(a[i], b[i], acc);
+      if (kb0 + i * stride < nkb) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) mfma_block<T, MT>(a[i], b[i][hf], acc[hf]);
+      }
     }
   }
 
-  // cross-wave reduction through LDS, then one fp32 slab row segment (64 B) per (row, n-tile)
-  __shared__ float red[4][MT][256];
+  // cross-wave reduction through LDS
+  __shared__ float red[4][NH][MT][256];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][mt][e * 64 + lane] = acc[mt][e];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][hf][mt][e * 64 + lane] = acc[hf][mt][e];
   __syncthreads();
   const int t = threadIdx.x;
   const int e = t >> 6, l2 = t & 63;
@@ -165,8 +183,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x,
   for (int mt = 0; mt < MT; ++mt) {
     const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
     if (row < M) {
-      float s = red[0][mt][t] + red[1][mt][t] + red[2][mt][t] + red[3][mt][t];
-      slabs[((size_t)split * M + row) * N + col] = s;
+      const float s0 = red[0][0][mt][t] + red[1][0][mt][t] + red[2][0][mt][t] + red[3][0][mt][t];
+      if constexpr (DUAL) {
+        const float s1 = red[0][1][mt][t] + red[1][1][mt][t] + red[2][1][mt][t] + red[3][1][mt][t];
+        const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
+        DT<T>::st(gout + (size_t)row * N + col, DT<T>::rt(silu_f(av)) * bv);
+      } else {
+        slabs[((size_t)split * M + row) * N + col] = s0;
+      }
     }
   }
 }
@@ -231,14 +255,33 @@ int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* spli
   }
   dim3 grid(N / 16, mchunks, splits);
   if (mt == 4)
-    gemm_mfma_kernel<T, 4><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+    gemm_mfma_kernel<T, 4, false><<<grid, 256, 0, st>>>(x, w, ws, nullptr, M, N, K);
   else if (mt == 2)
-    gemm_mfma_kernel<T, 2><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+    gemm_mfma_kernel<T, 2, false><<<grid, 256, 0, st>>>(x, w, ws, nullptr, M, N, K);
   else
-    gemm_mfma_kernel<T, 1><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+    gemm_mfma_kernel<T, 1, false><<<grid, 256, 0, st>>>(x, w, ws, nullptr, M, N, K);
   *splits_out = splits;
   return VLG_OK;
 }
+
+// g[M, F] = rt(rt(silu(rt(x @ w1^T))) * rt(x @ w3^T)) with w13 = [w1; w3] ([2F, K]).  Returns false if the shape needs the
+// generic path (gemm_slabs + reduce_silu_mul).
+template <typename T>
+bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_t st) {
+  constexpr int KBLK = GemmT<T>::KBLK;
+  if (K % KBLK != 0 || F % 16 != 0) return false;
+  const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
+  dim3 grid(F / 16, cdiv(M, mt * 16), 1);
+  if (mt == 4)
+    gemm_mfma_kernel<T, 4, true><<<grid, 256, 0, st>>>(x, w13, nullptr, g, M, F, K);
+  else if (mt == 2)
+    gemm_mfma_kernel<T, 2, true><<<grid, 256, 0, st>>>(x, w13, nullptr, g, M, F, K);
+  else
+    gemm_mfma_kernel<T, 1, true><<<grid, 256, 0, st>>>(x, w13, nullptr, g, M, F, K);
+  return true;
+}
+template bool gemm_swiglu<float>(const float*, const float*, float*, int, int, int, hipStream_t);
+template bool gemm_swiglu<bf16>(const bf16*, const bf16*, bf16*, int, int, int, hipStream_t);
 template int gemm_slabs<float>(const float*, const float*, float*, int, int, int, int*, hipStream_t);
 template int gemm_slabs<bf16>(const bf16*, const bf16*, float*, int, int, int, int*, hipStream_t);
 
@@ -267,56 +310,64 @@ int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int
 template int reduce_store<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
 template int reduce_store<bf16>(const float*, int, bf16*, float*, int, int, int, hipStream_t);
 
-template <typename T>
+template <typename T, int NE>
 __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ ws, int splits,
                                                                       T* __restrict__ h, const T* __restrict__ w,
                                                                       T* __restrict__ hn, int M, int D, float eps) {
-  constexpr int NE = 8;  // elements per thread per sweep (D <= 2048 in one sweep)
+  // one workgroup per row, the whole row in registers (D <= 256*NE): a single load -> reduce -> store chain
   __shared__ float red[4];
   const int m = blockIdx.x;
   T* hr = h + (size_t)m * D;
-  float ss = 0.f;
-  for (int base = 0; base < D; base += 256 * NE) {
-    float v[NE], s[NE];
+  float v[NE], s[NE], g[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = base + e * 256 + threadIdx.x;
-      v[e] = i < D ? DT<T>::ld(hr + i) : 0.f;
-      s[e] = 0.f;
-    }
-    if (ws) {
-      for (int k = 0; k < splits; ++k) {
-        const float* row = ws + ((size_t)k * M + m) * D;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const int i = base + e * 256 + threadIdx.x;
-          if (i < D) s[e] += row[i];
-        }
-      }
+  for (int e = 0; e < NE; ++e) {
+    const int i = e * 256 + threadIdx.x;
+    v[e] = i < D ? DT<T>::ld(hr + i) : 0.f;
+    g[e] = i < D ? DT<T>::ld(w + i) : 0.f;
+    s[e] = 0.f;
+  }
+  if (ws) {
+    for (int k = 0; k < splits; ++k) {
+      const float* row = ws + ((size_t)k * M + m) * D;
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
-        const int i = base + e * 256 + threadIdx.x;
-        if (i < D) {
-          v[e] = DT<T>::rt(v[e] + DT<T>::rt(s[e]));
-          DT<T>::st(hr + i, v[e]);
-        }
+        const int i = e * 256 + threadIdx.x;
+        if (i < D) s[e] += row[i];
       }
     }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) ss += v[e] * v[e];
+    for (int e = 0; e < NE; ++e) {
+      const int i = e * 256 + threadIdx.x;
+      if (i < D) {
+        v[e] = DT<T>::rt(v[e] + DT<T>::rt(s[e]));
+        DT<T>::st(hr + i, v[e]);
+      }
+    }
   }
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) ss += v[e] * v[e];
   ss = block_sum_256(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)D + eps);
-  for (int i = threadIdx.x; i < D; i += 256) {
-    float v = DT<T>::ld(hr + i);  // own store above: same thread, same address
-    float n = DT<T>::rt(v * rs);
-    DT<T>::st(hn + (size_t)m * D + i, n * DT<T>::ld(w + i));
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int i = e * 256 + threadIdx.x;
+    if (i < D) DT<T>::st(hn + (size_t)m * D + i, DT<T>::rt(v[e] * rs) * g[e]);
   }
 }
 
 template <typename T>
 int reduce_residual_rmsnorm(const float* ws, int splits, T* h, const T* w, T* hn, int M, int D, float eps, hipStream_t st) {
-  reduce_residual_rmsnorm_kernel<T><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  if (D <= 256 * 4)
+    reduce_residual_rmsnorm_kernel<T, 4><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else if (D <= 256 * 8)
+    reduce_residual_rmsnorm_kernel<T, 8><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else if (D <= 256 * 16)
+    reduce_residual_rmsnorm_kernel<T, 16><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else {
+    set_error("rmsnorm: dim %d > 4096 not supported", D);
+    return VLG_ERR_UNSUPPORTED;
+  }
   return VLG_OK;
 }
 template int reduce_residual_rmsnorm<float>(const float*, int, float*, const float*, float*, int, int, float, hipStream_t);
@@ -408,16 +459,26 @@ template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, cons
 //   with the usual (m, l, acc) rescale.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
-struct alignas(VEC * sizeof(T)) Pack {
+struct alignas((VEC * sizeof(T)) > 16 ? 16 : (VEC * sizeof(T))) Pack {
   T v[VEC];
 };
 
-template <typename T, int HD, int VEC, int LPR>
-__global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__ qbuf, const T* __restrict__ kc,
-                                                           const T* __restrict__ vc, float* __restrict__ ws,
+// FUSED (decode, Tq == 1): the kernel consumes the QKV GEMM's fp32 slabs directly - it sums the split-K partials of its own
+// (row, head) slice, applies RoPE to q and to the new key (gpt.py:221-222), and the workgroup whose key range contains
+// position p writes the new K/V row into the cache (gpt.py:182-183) while using the in-register copy for its own
+// score - one kernel less per layer and no q buffer round trip.
+struct FusedQKV {
+  const float* ws;      // [splits][M][3*H*HD]
+  int splits;
+  const float* freqs;   // [npos][HD/2][2]
+};
+
+template <typename T, int HD, int VEC, int LPR, bool FUSED>
+__global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__ qbuf, T* __restrict__ kc,
+                                                           T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
-                                                           int Tc, float scale) {
+                                                           int Tc, float scale, FusedQKV fq) {
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load
   constexpr int U = 4;           // loads in flight per operand
   constexpr int TILE = RPI * U;
@@ -435,13 +496,49 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
   const int coff = active ? c * VEC : 0;
 
   float qf[VEC];
-  {
+  Pack<T, VEC> knew, vnew;
+  bool own_p = false;
+  if constexpr (FUSED) {
+    static_assert(VEC % 2 == 0, "RoPE pairs must stay inside one lane");
+    const int M = gridDim.z, D3 = 3 * H * HD;
+    own_p = (r0 <= p && p < r1);
+    // unconditional, vectorised slab reads (every workgroup sums q, k and v: a per-element "load or not" select makes
+    // hipcc branch around each load and serialise them - cdna_hip_programming.md §5 trap (c))
+    float sq[VEC], sk[VEC], sv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sq[j] = sk[j] = sv[j] = 0.f;
+    for (int k = 0; k < fq.splits; ++k) {
+      const float* row = fq.ws + ((size_t)k * M + m) * D3 + h * HD + coff;
+      const Pack<float, VEC> pq = *reinterpret_cast<const Pack<float, VEC>*>(row);
+      const Pack<float, VEC> pk = *reinterpret_cast<const Pack<float, VEC>*>(row + H * HD);
+      const Pack<float, VEC> pv = *reinterpret_cast<const Pack<float, VEC>*>(row + 2 * H * HD);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        sq[j] += pq.v[j];
+        sk[j] += pk.v[j];
+        sv[j] += pv.v[j];
+      }
+    }
+    const float* fr = fq.freqs + ((size_t)p * (HD / 2) + coff / 2) * 2;
+#pragma unroll
+    for (int j = 0; j < VEC; j += 2) {
+      const float c = fr[j], sn = fr[j + 1];
+      const float q0 = DT<T>::rt(sq[j]), q1 = DT<T>::rt(sq[j + 1]);
+      qf[j] = active ? DT<T>::rt(__fsub_rn(__fmul_rn(q0, c), __fmul_rn(q1, sn))) : 0.f;
+      qf[j + 1] = active ? DT<T>::rt(__fadd_rn(__fmul_rn(q1, c), __fmul_rn(q0, sn))) : 0.f;
+      const float k0 = DT<T>::rt(sk[j]), k1 = DT<T>::rt(sk[j + 1]);
+      DT<T>::st(&knew.v[j], __fsub_rn(__fmul_rn(k0, c), __fmul_rn(k1, sn)));
+      DT<T>::st(&knew.v[j + 1], __fadd_rn(__fmul_rn(k1, c), __fmul_rn(k0, sn)));
+      DT<T>::st(&vnew.v[j], sv[j]);
+      DT<T>::st(&vnew.v[j + 1], sv[j + 1]);
+    }
+  } else {
     const Pack<T, VEC> qp = *reinterpret_cast<const Pack<T, VEC>*>(qbuf + ((size_t)m * H + h) * HD + coff);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) qf[j] = active ? DT<T>::ld(&qp.v[j]) : 0.f;
   }
-  const T* kbase = kc + ((size_t)b * H + h) * (size_t)S * HD + coff;
-  const T* vbase = vc + ((size_t)b * H + h) * (size_t)S * HD + coff;
+  T* kbase = kc + ((size_t)b * H + h) * (size_t)S * HD + coff;
+  T* vbase = vc + ((size_t)b * H + h) * (size_t)S * HD + coff;
   const float* mrow = (mask != nullptr) ? mask + (size_t)(b % Bmask) * Tc : nullptr;
 
   float mx = -INFINITY, l = 0.f, acc[VEC];
@@ -457,6 +554,19 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
       const int rr = rows[u] < r1 ? rows[u] : r1 - 1;
       kk[u] = *reinterpret_cast<const Pack<T, VEC>*>(kbase + (size_t)rr * HD);
       vv[u] = *reinterpret_cast<const Pack<T, VEC>*>(vbase + (size_t)rr * HD);
+      if constexpr (FUSED) {
+        // row p (the row this step appends) is not in the cache yet: every lane that addresses it - its owner and the
+        // out-of-range lanes clamped onto it - takes the in-register copy (stale cache bits could be NaN: 0 * NaN);
+        // the owner publishes it.
+        if (own_p && rr == p) {
+          kk[u] = knew;
+          vv[u] = vnew;
+          if (active && rows[u] == p) {
+            *reinterpret_cast<Pack<T, VEC>*>(kbase + (size_t)p * HD) = knew;
+            *reinterpret_cast<Pack<T, VEC>*>(vbase + (size_t)p * HD) = vnew;
+          }
+        }
+      }
     }
     float s[U];
     float tmax = -INFINITY;
@@ -553,8 +663,9 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
 size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 2); }
 
 template <typename T, int HD, int VEC, int LPR>
-static int attn_launch(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
-                       int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
+                       int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                       const FusedQKV* fq) {
   const int M = Bp * Tq;
   int nsplit = 2048 / (M * H);
   const int by_len = (max_pos + 1 + 63) / 64;
@@ -563,17 +674,31 @@ static int attn_launch(const T* qbuf, const T* kc, const T* vc, T* out, float* w
   if (nsplit < 1) nsplit = 1;
   const float scale = 1.0f / sqrtf((float)HD);
   if (ev0) (void)hipEventRecord(ev0, st);
-  attn_partial_kernel<T, HD, VEC, LPR><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale);
+  if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
+    if constexpr (VEC % 2 == 0)
+      attn_partial_kernel<T, HD, VEC, LPR, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc,
+                                                                                   scale, *fq);
+  } else {
+    if (fq != nullptr) {
+      set_error("fused qkv attention needs Tq == 1");
+      return VLG_ERR_BAD_ARG;
+    }
+    attn_partial_kernel<T, HD, VEC, LPR, false><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc,
+                                                                                    scale, FusedQKV{nullptr, 0, nullptr});
+  }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (nsplit > 1) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
   return VLG_OK;
 }
 
 template <typename T>
-int attn_rows(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
-              int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
+              int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+              const float* qkv_ws, int qkv_splits, const float* freqs) {
+  FusedQKV fqv{qkv_ws, qkv_splits, freqs};
+  const FusedQKV* fq = qkv_ws ? &fqv : nullptr;
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -591,34 +716,35 @@ int attn_rows(const T* qbuf, const T* kc, const T* vc, T* out, float* ws, const 
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, const float*, const float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t);
-template int attn_rows<bf16>(const bf16*, const bf16*, const bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ table, const I* __restrict__ idx, int n_idx,
-                                                          int null_id, T* __restrict__ out, int rows, int D) {
+                                                          int null_id, T* __restrict__ out, int rows, int D, int n_rows) {
   const int r = blockIdx.x;
-  const long long id = r < n_idx ? (long long)idx[r] : (long long)null_id;
+  long long id = r < n_idx ? (long long)idx[r] : (long long)null_id;
+  id = id < 0 ? 0 : (id >= n_rows ? n_rows - 1 : id);   // never fault on a bad id
   const T* src = table + (size_t)id * D;
   for (int i = threadIdx.x; i < D; i += 256) out[(size_t)r * D + i] = src[i];
 }
 template <typename T>
-int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, hipStream_t st) {
-  gather_rows_kernel<T, int32_t><<<rows, 256, 0, st>>>(table, idx, rows, 0, out, rows, D);
+int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st) {
+  gather_rows_kernel<T, int32_t><<<rows, 256, 0, st>>>(table, idx, rows, 0, out, rows, D, n_rows);
   return VLG_OK;
 }
 template <typename T>
-int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, hipStream_t st) {
-  gather_rows_kernel<T, int64_t><<<rows, 256, 0, st>>>(table, idx, n_idx, null_id, out, rows, D);
+int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, int n_rows, hipStream_t st) {
+  gather_rows_kernel<T, int64_t><<<rows, 256, 0, st>>>(table, idx, n_idx, null_id, out, rows, D, n_rows);
   return VLG_OK;
 }
-template int gather_rows_i32<float>(const float*, const int32_t*, float*, int, int, hipStream_t);
-template int gather_rows_i32<bf16>(const bf16*, const int32_t*, bf16*, int, int, hipStream_t);
-template int gather_rows_i64<float>(const float*, const int64_t*, int, int, float*, int, int, hipStream_t);
-template int gather_rows_i64<bf16>(const bf16*, const int64_t*, int, int, bf16*, int, int, hipStream_t);
+template int gather_rows_i32<float>(const float*, const int32_t*, float*, int, int, int, hipStream_t);
+template int gather_rows_i32<bf16>(const bf16*, const int32_t*, bf16*, int, int, int, hipStream_t);
+template int gather_rows_i64<float>(const float*, const int64_t*, int, int, float*, int, int, int, hipStream_t);
+template int gather_rows_i64<bf16>(const bf16*, const int64_t*, int, int, bf16*, int, int, int, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(256) void build_text_cond_kernel(const float* __restrict__ cond, const T* __restrict__ uncond,
@@ -674,7 +800,7 @@ template int latent_to_rows<bf16>(const float*, bf16*, int, int, int, hipStream_
 template <typename T>
 __global__ void latent_head_finish_kernel(const T* __restrict__ y, float* __restrict__ cur, float* __restrict__ out_lat,
                                           float* __restrict__ trace, const StepState* __restrict__ state, int B, int Bp, int C,
-                                          int N, float cfg_scale, int cfg_interval) {
+                                          int N, float cfg_scale, int cfg_interval, int b_off, int B_total) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, cidx = i % C;
@@ -690,16 +816,17 @@ __global__ void latent_head_finish_kernel(const T* __restrict__ y, float* __rest
   }
   cur[i] = v;
   out_lat[((size_t)b * N + step) * C + cidx] = v;
-  if (trace) trace[((size_t)step * B + b) * C + cidx] = v;
+  if (trace) trace[((size_t)step * B_total + b_off + b) * C + cidx] = v;
 }
 template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int N,
-                       float cfg_scale, int cfg_interval, hipStream_t st) {
-  latent_head_finish_kernel<T><<<cdiv(B * C, 256), 256, 0, st>>>(y, cur, out_lat, trace, state, B, Bp, C, N, cfg_scale, cfg_interval);
+                       float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total) {
+  latent_head_finish_kernel<T><<<cdiv(B * C, 256), 256, 0, st>>>(y, cur, out_lat, trace, state, B, Bp, C, N, cfg_scale, cfg_interval, b_off,
+                                                                 B_total > 0 ? B_total : B);
   return VLG_OK;
 }
-template int latent_head_finish<float>(const float*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t);
-template int latent_head_finish<bf16>(const bf16*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t);
+template int latent_head_finish<float>(const float*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
+template int latent_head_finish<bf16>(const bf16*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
 
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
                                                     int sample_logits, uint64_t seed, const float* __restrict__ noise,
                                                     const StepState* __restrict__ state, int fixed_step, int N,
                                                     int32_t* __restrict__ out_ids, int32_t* __restrict__ cur_tok,
-                                                    float* __restrict__ trace, float* __restrict__ probs_out) {
+                                                    float* __restrict__ trace, float* __restrict__ probs_out, int b_off, int B_total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   __shared__ Smem sm;
   const int b = blockIdx.x, t = threadIdx.x;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
         const float u = logits[(size_t)(b + B) * V + v];
         val = __fadd_rn(u, __fmul_rn(__fsub_rn(val, u), cfg_scale));   // generate.py:82
       }
-      if (trace) trace[((size_t)step * B + b) * V + v] = val;
+      if (trace) trace[((size_t)step * B_total + b_off + b) * V + v] = val;
       val = __fdiv_rn(val, tdiv);                                        // generate.py:58
     }
     x[i] = val;
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
       if (probs_out) probs_out[(size_t)b * V + v] = p;
       float sc = p;
       if (sample_logits) {
-        const float q = noise ? noise[((size_t)step * B + b) * V + v] : exp1_noise(seed, (uint32_t)step, (uint32_t)b, (uint32_t)v);
+        const float q = noise ? noise[((size_t)step * B_total + b_off + b) * V + v]
+                              : exp1_noise(seed, (uint32_t)step, (uint32_t)(b_off + b), (uint32_t)v);
         sc = __fdiv_rn(p, q);
       }
       if (sc > best || (sc == best && v < besti)) {
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
         besti = sm.redi[i];
       }
     }
+    if (besti < 0 || besti >= V) besti = 0;   // all-NaN row: never hand an invalid id to the next step's gather
     if (out_ids) out_ids[(size_t)b * N + step] = besti;
     if (cur_tok) {
       cur_tok[b] = besti;
@@ -306,7 +308,8 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
 
 int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampling_params& sp, const float* noise,
                 const StepState* state, int fixed_step, int N, int32_t* out_ids, int32_t* cur_tok, float* trace, float* probs,
-                hipStream_t st) {
+                hipStream_t st, int b_off, int B_total) {
+  if (B_total <= 0) B_total = B;
   if (V > VMAX || V < 1) {
     set_error("sampler: vocab %d not supported (max %d)", V, VMAX);
     return VLG_ERR_UNSUPPORTED;
@@ -326,11 +329,11 @@ int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampli
     }
     sample_kernel<true><<<B, NT, dyn, st>>>(logits, B, V, cfg_on ? 1 : 0, sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k,
                                             sp.top_p, sp.sample_logits, sp.seed, noise, state, fixed_step, N, out_ids, cur_tok, trace,
-                                            probs);
+                                            probs, b_off, B_total);
   } else {
     sample_kernel<false><<<B, NT, 0, st>>>(logits, B, V, cfg_on ? 1 : 0, sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k,
                                            sp.top_p, sp.sample_logits, sp.seed, noise, state, fixed_step, N, out_ids, cur_tok, trace,
-                                           probs);
+                                           probs, b_off, B_total);
   }
   return VLG_OK;
 }
