@@ -284,6 +284,7 @@ def test_unfused_qkv_path_matches_fused(golden, dt):
     cfg = cases.TINY_HD100 if dt == "fp32" else cases.TINY_C2I
     m, _ = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16)
     cond, _ = _inputs(cfg)
+    m.fuse_qkv = True
     a, ta = V.generate(m, cond, 16, cfg_scale=2.5, sample_logits=False, return_trace=True)
     m.fuse_qkv = False
     b, tb = V.generate(m, cond, 16, cfg_scale=2.5, sample_logits=False, return_trace=True)

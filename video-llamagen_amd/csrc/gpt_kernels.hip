@@ -21,6 +21,11 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+template <typename T, int VEC>
+struct alignas((VEC * sizeof(T)) > 16 ? 16 : (VEC * sizeof(T))) Pack {
+  T v[VEC];
+};
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
@@ -293,8 +298,12 @@ __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restri
                                                            float* __restrict__ out_f32, long long MN, int act) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= MN) return;
-  float s = ws[i];
-  for (int k = 1; k < splits; ++k) s += ws[(size_t)k * MN + i];
+  float part[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) part[k] = k < splits ? ws[(size_t)k * MN + i] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += part[k];
   s = DT<T>::rt(s);
   if (act == ACT_GELU_TANH) s = DT<T>::rt(gelu_tanh_f(s));
   if (out) DT<T>::st(out + i, s);
@@ -310,64 +319,96 @@ int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int
 template int reduce_store<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
 template int reduce_store<bf16>(const float*, int, bf16*, float*, int, int, int, hipStream_t);
 
-template <typename T, int NE>
+// NV = 4-element vectors per thread (row = 256 threads x NV x 4 elements): one workgroup per row, the whole row in
+// registers, every split-K slab requested up front (compile-time bound, predicated) with 16-byte loads.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ ws, int splits,
                                                                       T* __restrict__ h, const T* __restrict__ w,
                                                                       T* __restrict__ hn, int M, int D, float eps) {
-  // one workgroup per row, the whole row in registers (D <= 256*NE): a single load -> reduce -> store chain
   __shared__ float red[4];
   const int m = blockIdx.x;
   T* hr = h + (size_t)m * D;
-  float v[NE], s[NE], g[NE];
+  float v[NV][4], g[NV][4];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int i = e * 256 + threadIdx.x;
-    v[e] = i < D ? DT<T>::ld(hr + i) : 0.f;
-    g[e] = i < D ? DT<T>::ld(w + i) : 0.f;
-    s[e] = 0.f;
+  for (int e = 0; e < NV; ++e) {
+    const int i = (e * 256 + threadIdx.x) * 4;
+    if (i < D) {
+      const Pack<T, 4> pv = *reinterpret_cast<const Pack<T, 4>*>(hr + i);
+      const Pack<T, 4> pg = *reinterpret_cast<const Pack<T, 4>*>(w + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[e][j] = DT<T>::ld(&pv.v[j]);
+        g[e][j] = DT<T>::ld(&pg.v[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[e][j] = g[e][j] = 0.f;
+    }
   }
   if (ws) {
-    for (int k = 0; k < splits; ++k) {
-      const float* row = ws + ((size_t)k * M + m) * D;
+    float4 part[8][NV];
 #pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int i = e * 256 + threadIdx.x;
-        if (i < D) s[e] += row[i];
+    for (int k = 0; k < 8; ++k) {
+      const float* row = ws + ((size_t)(k < splits ? k : 0) * M + m) * D;
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const int i = (e * 256 + threadIdx.x) * 4;
+        part[k][e] = (k < splits && i < D) ? *reinterpret_cast<const float4*>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = e * 256 + threadIdx.x;
+    for (int e = 0; e < NV; ++e) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s[0] += part[k][e].x;
+        s[1] += part[k][e].y;
+        s[2] += part[k][e].z;
+        s[3] += part[k][e].w;
+      }
+      const int i = (e * 256 + threadIdx.x) * 4;
       if (i < D) {
-        v[e] = DT<T>::rt(v[e] + DT<T>::rt(s[e]));
-        DT<T>::st(hr + i, v[e]);
+        Pack<T, 4> po;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[e][j] = DT<T>::rt(v[e][j] + DT<T>::rt(s[j]));
+          DT<T>::st(&po.v[j], v[e][j]);
+        }
+        *reinterpret_cast<Pack<T, 4>*>(hr + i) = po;
       }
     }
   }
   float ss = 0.f;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) ss += v[e] * v[e];
+  for (int e = 0; e < NV; ++e)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss += v[e][j] * v[e][j];
   ss = block_sum_256(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)D + eps);
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int i = e * 256 + threadIdx.x;
-    if (i < D) DT<T>::st(hn + (size_t)m * D + i, DT<T>::rt(v[e] * rs) * g[e]);
+  for (int e = 0; e < NV; ++e) {
+    const int i = (e * 256 + threadIdx.x) * 4;
+    if (i < D) {
+      Pack<T, 4> po;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) DT<T>::st(&po.v[j], DT<T>::rt(v[e][j] * rs) * g[e][j]);
+      *reinterpret_cast<Pack<T, 4>*>(hn + (size_t)m * D + i) = po;
+    }
   }
 }
 
 template <typename T>
 int reduce_residual_rmsnorm(const float* ws, int splits, T* h, const T* w, T* hn, int M, int D, float eps, hipStream_t st) {
-  if (D <= 256 * 4)
-    reduce_residual_rmsnorm_kernel<T, 4><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
-  else if (D <= 256 * 8)
-    reduce_residual_rmsnorm_kernel<T, 8><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
-  else if (D <= 256 * 16)
-    reduce_residual_rmsnorm_kernel<T, 16><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
-  else {
-    set_error("rmsnorm: dim %d > 4096 not supported", D);
+  if (D % 4 != 0 || D > 4096 || splits > 8) {
+    set_error("rmsnorm: dim %d / splits %d not supported (dim %% 4 == 0, dim <= 4096)", D, splits);
     return VLG_ERR_UNSUPPORTED;
   }
+  if (D <= 1024)
+    reduce_residual_rmsnorm_kernel<T, 1><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else if (D <= 2048)
+    reduce_residual_rmsnorm_kernel<T, 2><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else
+    reduce_residual_rmsnorm_kernel<T, 4><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
   return VLG_OK;
 }
 template int reduce_residual_rmsnorm<float>(const float*, int, float*, const float*, float*, int, int, float, hipStream_t);
@@ -419,10 +460,14 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
   const int b = m / Tq, t = m % Tq;
   const int p = state->pos + t;
   float x0 = 0.f, x1 = 0.f;
-  for (int k = 0; k < splits; ++k) {
-    const float2 v = *reinterpret_cast<const float2*>(ws + ((size_t)k * M + m) * (3 * (size_t)D) + col);
-    x0 += v.x;
-    x1 += v.y;
+  float2 part[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    part[k] = k < splits ? *reinterpret_cast<const float2*>(ws + ((size_t)k * M + m) * (3 * (size_t)D) + col) : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    x0 += part[k].x;
+    x1 += part[k].y;
   }
   x0 = DT<T>::rt(x0);
   x1 = DT<T>::rt(x1);
@@ -458,10 +503,6 @@ template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, cons
 //   Each lane group keeps its own online-softmax state (m, l, acc[VEC]); groups -> waves -> splits are merged
 //   with the usual (m, l, acc) rescale.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
-struct alignas((VEC * sizeof(T)) > 16 ? 16 : (VEC * sizeof(T))) Pack {
-  T v[VEC];
-};
 
 // FUSED (decode, Tq == 1): the kernel consumes the QKV GEMM's fp32 slabs directly - it sums the split-K partials of its own
 // (row, head) slice, applies RoPE to q and to the new key (gpt.py:221-222), and the workgroup whose key range contains
@@ -667,7 +708,9 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                        const FusedQKV* fq) {
   const int M = Bp * Tq;
-  int nsplit = 2048 / (M * H);
+  // one balanced round of workgroups: the kernel holds 6 workgroups per CU (76 VGPRs -> 6 waves/SIMD), 256 CUs.
+  // B'H = 640 (GPT-XL, 32 rows) -> nsplit 2 -> 1280 workgroups = exactly 5 per CU, no second-round tail.
+  int nsplit = 1536 / (M * H);
   const int by_len = (max_pos + 1 + 63) / 64;
   if (nsplit > by_len) nsplit = by_len;
   if (nsplit > 16) nsplit = 16;

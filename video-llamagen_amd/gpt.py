@@ -107,7 +107,7 @@ class Transformer:
         self.use_graph = True
         self.time_attn = False
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
-        self.fuse_qkv = True    # decode: RoPE + KV append fused into the attention kernel
+        self.fuse_qkv = False    # decode: RoPE + KV append fused into the attention kernel
         self.lanes = 0          # 0 = auto: independent batch lanes on forked graph branches (see csrc/gpt.hip)
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
