@@ -35,26 +35,7 @@ def build_gpt(V, a, device):
                                   vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4,
                                   caption_dim=2048)
     m.to(device=device, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).eval()
-    c = m.config
-    D = c.dim
-    F = (int(2 * 4 * D / 3) + 255) // 256 * 256
-    g = torch.Generator(device=device).manual_seed(1234)
-
-    def rnd(*shape, std=0.02):
-        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std)
-
-    sd = {"cls_embedding.cap_proj.fc1.weight": rnd(D, 2048), "cls_embedding.cap_proj.fc2.weight": rnd(D, D),
-          "cls_embedding.uncond_embedding": rnd(120, 2048, std=2048 ** -0.5),
-          "vae_latent_adapter.fc1.weight": rnd(D, a.vae_embed_dim, std=0.3), "vae_latent_adapter.fc2.weight": rnd(D, D),
-          "vae_latent_adapter2.fc1.weight": rnd(D, D), "vae_latent_adapter2.fc2.weight": rnd(a.vae_embed_dim, D, std=0.3),
-          "norm.weight": 1 + rnd(D, std=0.1)}
-    m.load_state_dict(sd, strict=False)
-    for i in range(c.n_layer):
-        p = f"layers.{i}."
-        m.load_state_dict({p + "attention.wqkv.weight": rnd(3 * D, D), p + "attention.wo.weight": rnd(D, D),
-                           p + "feed_forward.w1.weight": rnd(F, D), p + "feed_forward.w3.weight": rnd(F, D),
-                           p + "feed_forward.w2.weight": rnd(D, F), p + "attention_norm.weight": 1 + rnd(D, std=0.1),
-                           p + "ffn_norm.weight": 1 + rnd(D, std=0.1)}, strict=False)
+    m.init_random_weights(seed=1234)
     return m
 
 
@@ -200,8 +181,15 @@ def main():
         ms, by, n = gpt.attn_timing()
         if n > 0 and ms > 0:
             ach = by / (ms * 1e-3) / 1e9
+            traffic, tsrc = None, None
+            try:   # HBM bytes per algorithmic byte measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction), see file
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_attn_fetch.json")))
+                ratio = float(np.mean([r["traffic_over_algorithmic"] for r in pmc["rows"] if r["pos"] >= 1000]))
+                traffic, tsrc = ratio * by / n, "profiles/r01_pmc_attn_fetch.json (FETCH_SIZE x2, ratio %.4f to algorithmic)" % ratio
+            except Exception:
+                pass
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "kernel": "attn_partial_kernel", "launches_timed": n,
+                               "traffic": traffic, "traffic_source": tsrc, "kernel": "attn_partial_kernel", "launches_timed": n,
                                "avg_launch_us": 1e3 * ms / n, "avg_algorithmic_bytes_per_launch": by / n}
         wb, kb, ob = gpt.algorithmic_bytes()
         res["algorithmic_bytes_per_step"] = {"weights": wb, "kv": kb, "other": ob}

@@ -625,12 +625,13 @@ extern "C" int vlg_attn_decode(const void* d_q, const void* d_k, const void* d_v
   VLG_CHECK(d_q && d_k && d_v && d_out && Bp > 0 && H > 0 && S > 0 && pos >= 0 && pos < S, VLG_ERR_BAD_ARG,
             "vlg_attn_decode: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  VLG_HIP(hipStreamSynchronize(st));
   Scratch& s = scratch();
-  VLG_TRY(s.aux.reserve(attn_ws_floats(Bp, H, hd) * sizeof(float)));
-  VLG_TRY(s.state.reserve(sizeof(StepState)));
-  const StepState ss{pos, 0};
-  VLG_HIP(hipMemcpy(s.state.p, &ss, sizeof(ss), hipMemcpyHostToDevice));
+  if (s.aux.bytes < attn_ws_floats(Bp, H, hd) * sizeof(float) || s.state.bytes < sizeof(StepState)) {
+    VLG_HIP(hipStreamSynchronize(st));
+    VLG_TRY(s.aux.reserve(attn_ws_floats(Bp, H, hd) * sizeof(float)));
+    VLG_TRY(s.state.reserve(sizeof(StepState)));
+  }
+  VLG_TRY(set_state(s.state.as<StepState>(), pos, 0, st));
   if (dtype == VLG_BF16)
     return attn_rows<bf16>((const bf16*)d_q, (bf16*)d_k, (bf16*)d_v, (bf16*)d_out, s.aux.as<float>(), s.state.as<StepState>(),
                            Bp, 1, H, hd, S, pos, d_mask, Bmask > 0 ? Bmask : 1, Tc, st);

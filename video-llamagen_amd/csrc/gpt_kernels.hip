@@ -13,6 +13,8 @@
 //     be had), 16 B per lane coalesced K/V rows, per-lane-group online softmax, DPP reductions;
 //   * every elementwise op (residual, RMSNorm, RoPE, KV scatter, SiLU*mul, GELU) lives in a slab-reduce
 //     epilogue kernel, rounding to the storage dtype exactly where the reference materialises a tensor.
+#include <stdlib.h>
+
 #include "gpt_kernels.h"
 
 namespace vlg {
@@ -29,6 +31,18 @@ struct alignas((VEC * sizeof(T)) > 16 ? 16 : (VEC * sizeof(T))) Pack {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// streamed-once data (KV rows, weights): non-temporal load so the stream does not evict what other kernels re-read
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_stream(const T* p) {
+  if constexpr (sizeof(Pack<T, VEC>) == 16) {
+    return __builtin_bit_cast(Pack<T, VEC>, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
+  } else if constexpr (sizeof(Pack<T, VEC>) == 8) {
+    return __builtin_bit_cast(Pack<T, VEC>, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p)));
+  } else {
+    return *reinterpret_cast<const Pack<T, VEC>*>(p);
+  }
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -514,14 +528,13 @@ struct FusedQKV {
   const float* freqs;   // [npos][HD/2][2]
 };
 
-template <typename T, int HD, int VEC, int LPR, bool FUSED>
+template <typename T, int HD, int VEC, int LPR, bool FUSED, int U>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__ qbuf, T* __restrict__ kc,
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
                                                            int Tc, float scale, FusedQKV fq) {
-  constexpr int RPI = 64 / LPR;  // rows per wave-wide load
-  constexpr int U = 4;           // loads in flight per operand
+  constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
   const int b = m / Tq, t = m % Tq;
@@ -593,8 +606,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
     for (int u = 0; u < U; ++u) {
       rows[u] = tile + u * RPI + g;
       const int rr = rows[u] < r1 ? rows[u] : r1 - 1;
-      kk[u] = *reinterpret_cast<const Pack<T, VEC>*>(kbase + (size_t)rr * HD);
-      vv[u] = *reinterpret_cast<const Pack<T, VEC>*>(vbase + (size_t)rr * HD);
+      kk[u] = load_stream<T, VEC>(kbase + (size_t)rr * HD);
+      vv[u] = load_stream<T, VEC>(vbase + (size_t)rr * HD);
       if constexpr (FUSED) {
         // row p (the row this step appends) is not in the cache yet: every lane that addresses it - its owner and the
         // out-of-range lanes clamped onto it - takes the in-register copy (stale cache bits could be NaN: 0 * NaN);
@@ -708,9 +721,10 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                        const FusedQKV* fq) {
   const int M = Bp * Tq;
-  // one balanced round of workgroups: the kernel holds 6 workgroups per CU (76 VGPRs -> 6 waves/SIMD), 256 CUs.
-  // B'H = 640 (GPT-XL, 32 rows) -> nsplit 2 -> 1280 workgroups = exactly 5 per CU, no second-round tail.
-  int nsplit = 1536 / (M * H);
+  // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
+  // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679; VLG_ATTN_CAP / VLG_ATTN_U are tuning knobs.
+  static const int cap_knob = getenv("VLG_ATTN_CAP") ? atoi(getenv("VLG_ATTN_CAP")) : 2560;
+  int nsplit = cap_knob / (M * H);
   const int by_len = (max_pos + 1 + 63) / 64;
   if (nsplit > by_len) nsplit = by_len;
   if (nsplit > 16) nsplit = 16;
@@ -719,15 +733,23 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
   if (ev0) (void)hipEventRecord(ev0, st);
   if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
     if constexpr (VEC % 2 == 0)
-      attn_partial_kernel<T, HD, VEC, LPR, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc,
-                                                                                   scale, *fq);
+      attn_partial_kernel<T, HD, VEC, LPR, true, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
+                                                                                      Tc, scale, *fq);
   } else {
     if (fq != nullptr) {
       set_error("fused qkv attention needs Tq == 1");
       return VLG_ERR_BAD_ARG;
     }
-    attn_partial_kernel<T, HD, VEC, LPR, false><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc,
-                                                                                    scale, FusedQKV{nullptr, 0, nullptr});
+    static const int u_knob = getenv("VLG_ATTN_U") ? atoi(getenv("VLG_ATTN_U")) : 4;
+    if (u_knob == 8)
+      attn_partial_kernel<T, HD, VEC, LPR, false, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
+    else if (u_knob == 2)
+      attn_partial_kernel<T, HD, VEC, LPR, false, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
+    else
+      attn_partial_kernel<T, HD, VEC, LPR, false, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (nsplit > 1) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);

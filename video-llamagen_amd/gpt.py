@@ -170,6 +170,57 @@ class Transformer:
             raise RuntimeError("Unexpected key(s) in state_dict: %s" % ", ".join(unexpected))
         return [], unexpected
 
+    def param_shapes(self):
+        """name -> shape of every tensor the sampling path needs (reference state-dict names)."""
+        c = self.config
+        D = c.dim
+        F = find_multiple(int(2 * (4 * D) / 3), c.multiple_of)          # gpt.py:154-159
+        out = {}
+        if c.model_type == 'c2i':
+            out["cls_embedding.embedding_table.weight"] = (c.num_classes + 1, D)
+        else:
+            out["cls_embedding.cap_proj.fc1.weight"] = (D, c.caption_dim)
+            out["cls_embedding.cap_proj.fc2.weight"] = (D, D)
+            out["cls_embedding.uncond_embedding"] = (120, c.caption_dim)
+        if c.model_type == 't2v':
+            out["vae_latent_adapter.fc1.weight"] = (D, c.vae_embed_dim)
+            out["vae_latent_adapter.fc2.weight"] = (D, D)
+            if self._head_code() == L.VLG_HEAD_ADAPTER2:
+                out["vae_latent_adapter2.fc1.weight"] = (D, D)
+                out["vae_latent_adapter2.fc2.weight"] = (c.vae_embed_dim, D)
+        else:
+            out["tok_embeddings.weight"] = (c.vocab_size, D)
+            out["output.weight"] = (c.vocab_size, D)
+        for i in range(c.n_layer):
+            p = "layers.%d." % i
+            out[p + "attention.wqkv.weight"] = (3 * D, D)
+            out[p + "attention.wo.weight"] = (D, D)
+            out[p + "feed_forward.w1.weight"] = (F, D)
+            out[p + "feed_forward.w3.weight"] = (F, D)
+            out[p + "feed_forward.w2.weight"] = (D, F)
+            out[p + "attention_norm.weight"] = (D,)
+            out[p + "ffn_norm.weight"] = (D,)
+        out["norm.weight"] = (D,)
+        return out
+
+    def init_random_weights(self, seed=0, std=None):
+        """Random initialisation on the device, stand-in for the reference constructor's `initialize_weights`
+        (gpt.py:302-316: N(0, 0.02) Linear/Embedding; `output.weight` is drawn too instead of zeroed)."""
+        self._ensure_handle()
+        std = self.config.initializer_range if std is None else std
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        for name, shape in self.param_shapes().items():
+            if name.endswith("norm.weight"):
+                t = torch.ones(shape, device=self._device)
+            elif name == "cls_embedding.uncond_embedding":
+                t = torch.randn(shape, generator=g, device=self._device) / shape[1] ** 0.5
+            elif name in ("vae_latent_adapter.fc1.weight", "vae_latent_adapter2.fc2.weight"):
+                t = torch.randn(shape, generator=g, device=self._device) * 0.3     # keeps O(1) latents for tiny embed dims
+            else:
+                t = torch.randn(shape, generator=g, device=self._device) * std
+            self.load_state_dict({name: t}, strict=False)
+        return self
+
     def setup_caches(self, max_batch_size, max_seq_length, dtype=None):
         """gpt.py:318-332.  The KV cache itself is (re)sized inside vlg_gpt_generate; this records the shape."""
         self.max_seq_length = find_multiple(max_seq_length, 8)

@@ -76,6 +76,69 @@ class VQModel:
                     skipped.append(k)       # encoder.*, quant_conv.*, codebook_used: not on the decode path
         return [], skipped
 
+    def decoder_param_shapes(self):
+        """name -> shape of the decode-side tensors (vq_model.py:32-39,137-167,207)."""
+        c = self.config
+        ch, mult, out = 128, list(c.decoder_ch_mult), {}
+
+        def conv(n, co, ci, k):
+            out[n + ".weight"] = (co, ci, k, k)
+            out[n + ".bias"] = (co,)
+
+        def gn(n, cch):
+            out[n + ".weight"] = (cch,)
+            out[n + ".bias"] = (cch,)
+
+        def res(p, ci, co):
+            gn(p + ".norm1", ci)
+            conv(p + ".conv1", co, ci, 3)
+            gn(p + ".norm2", co)
+            conv(p + ".conv2", co, co, 3)
+            if ci != co:
+                conv(p + ".nin_shortcut", co, ci, 1)
+
+        def attn(p, cch):
+            gn(p + ".norm", cch)
+            for n in ("q", "k", "v", "proj_out"):
+                conv(p + "." + n, cch, cch, 1)
+
+        out["quantize.embedding.weight"] = (c.codebook_size, c.codebook_embed_dim)
+        conv("post_quant_conv", c.z_channels, c.codebook_embed_dim, 1)
+        nres = len(mult)
+        block_in = ch * mult[nres - 1]
+        conv("decoder.conv_in", block_in, c.z_channels, 3)
+        res("decoder.mid.0", block_in, block_in)
+        attn("decoder.mid.1", block_in)
+        res("decoder.mid.2", block_in, block_in)
+        for li, lvl in enumerate(reversed(range(nres))):
+            block_out = ch * mult[lvl]
+            for j in range(3):
+                res("decoder.conv_blocks.%d.res.%d" % (li, j), block_in, block_out)
+                block_in = block_out
+                if lvl == nres - 1:
+                    attn("decoder.conv_blocks.%d.attn.%d" % (li, j), block_in)
+            if lvl != 0:
+                conv("decoder.conv_blocks.%d.upsample.conv" % li, block_in, block_in, 3)
+        gn("decoder.norm_out", block_in)
+        conv("decoder.conv_out", 3, block_in, 3)
+        return out
+
+    def init_random_weights(self, seed=0):
+        """Random initialisation on the device (stand-in for the reference constructor's default nn.Conv2d init)."""
+        self._ensure_handle()
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        for name, shape in self.decoder_param_shapes().items():
+            if len(shape) == 4:
+                t = torch.randn(shape, generator=g, device=self._device) * (0.7 / (shape[1] * shape[2] * shape[3]) ** 0.5)
+            elif name == "quantize.embedding.weight":
+                t = torch.randn(shape, generator=g, device=self._device)
+            elif ".norm" in name and name.endswith(".weight"):
+                t = torch.ones(shape, device=self._device)
+            else:
+                t = torch.zeros(shape, device=self._device)
+            self.load_state_dict({name: t})
+        return self
+
     @torch.no_grad()
     def decode_code(self, code_b, shape=None, channel_first=True):
         """code_b int [B, h*w] (or flat), shape = [B, C, h, w] -> float32 [B, 3, 16h, 16w] (NCHW)."""
