@@ -33,7 +33,7 @@ def log(*a):
 def build_gpt(V, a, device):
     m = V.GPT_models[a.gpt_model](block_size=a.latent ** 2, cls_token_num=120, model_type="t2v",
                                   vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4,
-                                  caption_dim=2048)
+                                  caption_dim=2048, head=a.head)
     m.to(device=device, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).eval()
     m.init_random_weights(seed=1234)
     return m
@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=0, help="debug: generate fewer than vae_t*latent^2 tokens")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--cfg-scale", type=float, default=1.0)
+    ap.add_argument("--head", default="adapter2", choices=["adapter2", "hidden"],
+                    help="t2v head: adapter2 (gpt_video.py MSE head, default) or hidden (gpt_video_diff.py DiffLoss, 100 DDPM steps/token)")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--vae-chunk", type=int, default=4, help="videos per vae.decode call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +165,7 @@ def main():
         "value": tokens / dt, "unit": "video tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"{a.gpt_model} t2v (adapter2 head), 120 text tokens + {N} latent tokens "
+        "config": {"workload": f"{a.gpt_model} t2v ({a.head} head), 120 text tokens + {N} latent tokens "
                                f"({vae_t}x{a.latent}x{a.latent}, vae_embed_dim {a.vae_embed_dim}), cfg {a.cfg_scale}, "
                                f"{B} videos per GPU, {'CausalVideoVAE decode to 17x256x256 included' if vae is not None else 'VAE decode NOT included'}",
                    "global_batch": world * B, "seq_len": 120 + N, "parallelism": f"batch-shard x{world}"},

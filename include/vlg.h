@@ -57,6 +57,8 @@ typedef struct {
   int32_t dtype;                     /* compute/storage dtype of weights, activations, KV    */
   int32_t multiple_of;               /* SwiGLU hidden rounding, gpt.py:29,154-159            */
   float norm_eps, rope_base;
+  /* VLG_HEAD_HIDDEN only: per-token diffusion head, gpt_video_diff.py:76-78 (DiffLoss)       */
+  int32_t diffloss_w, diffloss_d, num_sampling_steps;
 } vlg_gpt_config;
 
 int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out);
@@ -78,11 +80,13 @@ typedef struct {
   uint64_t seed;         /* Philox seed for the on-device Exp(1) noise when d_noise == NULL    */
 } vlg_sampling_params;
 
-/* replaces generate() autoregressive/models/generate.py:127-180 (c2i/t2i) and the skeleton of
- * generate_video_diff.py:185-228 with the gpt_video.py:431 head (t2v).
+/* replaces generate() autoregressive/models/generate.py:127-180 (c2i/t2i) and generate_video_diff.py:185-228 (t2v) with
+ * the gpt_video.py:431 adapter2 head or the DiffLoss.sample head (diffloss.py:35-52; cfg_scale must be 1 as in the
+ * reference's shipped scripts; sp->temperature scales the reverse-step noise).
  *   d_cond      c2i: int64 [B] class ids; t2i/t2v: fp32 [B, cls_token_num, caption_dim] (already * mask)
  *   d_emb_mask  fp32 [B, cls_token_num] (1 = valid, left-padded) or NULL
- *   d_noise     fp32 [N, B, vocab] Exp(1) draws consumed as argmax(p / q) or NULL (-> Philox(seed))
+ *   d_noise     logits head: fp32 [N, B, vocab] Exp(1) draws consumed as argmax(p / q); hidden (DiffLoss) head: fp32
+ *               [N, num_sampling_steps + 1, B, C] N(0,1) draws (x_T, then one per reverse step); NULL -> Philox(seed)
  *   d_out_ids   int32 [B, N]            (logits head)
  *   d_out_lat   fp32  [B, N, vae_embed_dim]  (adapter2 / hidden head)
  *   d_trace     optional fp32 [N, B, vocab|C]: the CFG-combined head output fed to the sampler */

@@ -10,6 +10,8 @@ TINY_T2I = dict(TINY_C2I, model_type="t2i", cls_token_num=120)  # uncond_embeddi
 TINY_T2V = dict(TINY_C2I, model_type="t2v", cls_token_num=8, block_size=16, vae_embed_dim=8,
                 num_frames=9, t_downsample_size=4, head="adapter2",
                 adapter_in_std=0.3, adapter_out_std=0.3)
+# t2v with the per-token diffusion head (gpt_video_diff.py): 10 sampling steps, width 128, depth 3
+TINY_T2V_DIFF = dict(TINY_T2V, head="hidden", diffloss_w=128, diffloss_d=3, num_sampling_steps=10)
 # hd = 100 (GPT-3B's head_dim, gpt.py:445) at toy width
 TINY_HD100 = dict(TINY_C2I, dim=200, n_head=2, block_size=16)
 

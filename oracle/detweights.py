@@ -55,6 +55,8 @@ def gpt_weights(cfg, seed=1234, std=0.02, head_std=0.02):
         if cfg.get("head", "adapter2") == "adapter2":
             sd["vae_latent_adapter2.fc1.weight"] = normal("vae_latent_adapter2.fc1.weight", (D, D), std, seed)
             sd["vae_latent_adapter2.fc2.weight"] = normal("vae_latent_adapter2.fc2.weight", (C, D), cfg.get("adapter_out_std", std), seed)
+        if cfg.get("head") == "hidden":
+            sd.update(diffloss_weights(D, C, cfg.get("diffloss_w", 1024), cfg.get("diffloss_d", 3), seed))
     sd["tok_embeddings.weight"] = normal("tok_embeddings.weight", (cfg["vocab_size"], D), std, seed)
     for i in range(cfg["n_layer"]):
         p = f"layers.{i}."
@@ -67,6 +69,32 @@ def gpt_weights(cfg, seed=1234, std=0.02, head_std=0.02):
         sd[p + "ffn_norm.weight"] = (1.0 + normal(p + "ffn_norm.weight", (D,), 0.1, seed)).astype(np.float32)
     sd["norm.weight"] = (1.0 + normal("norm.weight", (D,), 0.1, seed)).astype(np.float32)
     sd["output.weight"] = normal("output.weight", (cfg["vocab_size"], D), head_std, seed)
+    return sd
+
+
+def diffloss_weights(z_channels, target_channels, width, depth, seed=1234):
+    """diffloss.net.* (diffloss.py:161-190).  The reference zero-inits every adaLN / output layer (diffloss.py:206-215);
+    they are drawn non-zero here so the goldens exercise the whole network."""
+    sd = {}
+    p = "diffloss.net."
+
+    def lin(name, out_f, in_f, std=None):
+        sd[p + name + ".weight"] = normal(p + name + ".weight", (out_f, in_f), std if std else 1.0 / np.sqrt(in_f), seed)
+        sd[p + name + ".bias"] = normal(p + name + ".bias", (out_f,), 0.02, seed)
+
+    lin("time_embed.mlp.0", width, 256)
+    lin("time_embed.mlp.2", width, width)
+    lin("cond_embed", width, z_channels)
+    lin("input_proj", width, target_channels)
+    for i in range(depth):
+        b = f"res_blocks.{i}."
+        sd[p + b + "in_ln.weight"] = (1.0 + normal(p + b + "in_ln.weight", (width,), 0.1, seed)).astype(np.float32)
+        sd[p + b + "in_ln.bias"] = normal(p + b + "in_ln.bias", (width,), 0.05, seed)
+        lin(b + "mlp.0", width, width)
+        lin(b + "mlp.2", width, width, 0.5 / np.sqrt(width))
+        lin(b + "adaLN_modulation.1", 3 * width, width, 0.5 / np.sqrt(width))
+    lin("final_layer.adaLN_modulation.1", 2 * width, width, 0.5 / np.sqrt(width))
+    lin("final_layer.linear", 2 * target_channels, width, 0.5 / np.sqrt(width))
     return sd
 
 

@@ -49,6 +49,22 @@ def load_gpt_video():
     return mod
 
 
+def load_gpt_video_diff():
+    """exec gpt_video_diff.py:1-1091 (class part; needs autoregressive/models on sys.path for `from diffloss import`)."""
+    _install()
+    mdir = os.path.join(REF, "autoregressive/models")
+    if mdir not in sys.path:
+        sys.path.insert(0, mdir)
+    path = os.path.join(mdir, "gpt_video_diff.py")
+    src = open(path).read()
+    cut = src.index("from einops import rearrange, repeat")
+    mod = types.ModuleType("ref_gpt_video_diff")
+    mod.__file__ = path
+    exec(compile(src[:cut], path, "exec"), mod.__dict__)
+    gen = importlib.import_module("autoregressive.models.generate_video_diff")
+    return mod, gen
+
+
 def load_vae_modules():
     _install()
     root = os.path.join(REF, "CausalVideoVAE")

@@ -231,6 +231,61 @@ def gold_t2v(out):
         out[f"t2v_{dt_name}_latents"] = np.concatenate(outs, 1)
 
 
+def gold_t2vdiff(out):
+    """gpt_video_diff + DiffLoss head through the reference's own generate_video_diff.generate (B = 1, cfg 1: the only
+    mode the shipped code supports), 10 sampling steps, fixed noise fed through patched torch.randn / randn_like."""
+    gvd, gen = ref_harness.load_gpt_video_diff()
+    cfg = cases.TINY_T2V_DIFF
+    vae_t = (cfg["num_frames"] - 1) // cfg["t_downsample_size"] + 1
+    N = 6
+    S = cfg["num_sampling_steps"]
+    sd = detweights.gpt_weights(cfg)
+    args = gvd.ModelArgs(dim=cfg["dim"], n_layer=cfg["n_layer"], n_head=cfg["n_head"], vocab_size=cfg["vocab_size"],
+                         block_size=cfg["block_size"], cls_token_num=cfg["cls_token_num"], model_type="t2v", caption_dim=cfg["caption_dim"],
+                         vae_embed_dim=cfg["vae_embed_dim"], num_frames=cfg["num_frames"], t_downsample_size=cfg["t_downsample_size"],
+                         diffloss_d=cfg["diffloss_d"], diffloss_w=cfg["diffloss_w"], num_sampling_steps=str(S))
+    m = gvd.Transformer(args)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("freqs") or k in ("mask_token", "output.weight", "tok_embeddings.weight") for k in missing), missing
+    m = m.eval()
+    C = cfg["vae_embed_dim"]
+    noise = cases.rng(51).standard_normal((N, S + 1, 1, C), dtype=np.float32)
+    c, mk = cases.text_cond(1, cfg["cls_token_num"], cfg["caption_dim"], lens=[5])
+    calls = [0]
+    orig_randn, orig_like, orig_cuda = torch.randn, torch.randn_like, torch.Tensor.cuda
+
+    def nxt(shape):
+        tok, k = divmod(calls[0], S + 1)
+        calls[0] += 1
+        a = t(noise[tok, k])
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
+        return a.clone()
+
+    torch.randn = lambda *shape, **kw: nxt(shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape)
+    torch.randn_like = lambda x, **kw: nxt(x.shape)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        lat = gen.generate(m, t(c), N, t(mk), cfg_scale=1.0, temperature=0.9, cfg_iter=1.0)
+    finally:
+        torch.randn, torch.randn_like, torch.Tensor.cuda = orig_randn, orig_like, orig_cuda
+    assert calls[0] == N * (S + 1)
+    out["t2vdiff_latents"] = lat.float().numpy()
+    # schedule + one network evaluation for localisation
+    gd = m.diffloss.gen_diffusion
+    out["sched_timestep_map"] = np.array(gd.timestep_map, np.int64)
+    out["sched_sqrt_recip"] = gd.sqrt_recip_alphas_cumprod
+    out["sched_coef1"] = gd.posterior_mean_coef1
+    out["sched_min_log"] = gd.posterior_log_variance_clipped
+    out["sched_max_log"] = np.log(gd.betas)
+    x = t(cases.rng(52).standard_normal((3, C), dtype=np.float32))
+    z = t(cases.rng(53).standard_normal((3, cfg["dim"]), dtype=np.float32))
+    out["net_out"] = m.diffloss.net(x, torch.tensor([999, 444, 0]), z).numpy()
+    gd100 = gvd.DiffLoss(target_channels=8, z_channels=16, depth=1, width=16, num_sampling_steps="100").gen_diffusion
+    out["sched100_timestep_map"] = np.array(gd100.timestep_map, np.int64)
+    out["sched100_coef2"] = gd100.posterior_mean_coef2
+
+
 def gold_gptb(out):
     """BASELINE config 1: GPT-B c2i 16x16 greedy fp32, B=1: ids + top1-top2 margins."""
     gptmod, genmod = ref_harness.load_gpt()
@@ -244,7 +299,7 @@ def gold_gptb(out):
     out["gptb_top1"] = srt[:, -1].astype(np.float32)
 
 
-PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb)
+PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -322,3 +322,62 @@ def test_batch_lanes_do_not_change_results(golden, lanes):
     lat = V.generate_t2v(mv, torch.from_numpy(c), 48, torch.from_numpy(mk))
     ref = golden("t2v")["t2v_fp32_latents"]
     assert np.abs(to_np(lat) - ref).max() < 3e-4 * max(1.0, np.abs(ref).max())
+
+
+def _diff_model(dtype, steps=10):
+    cfg = dict(cases.TINY_T2V_DIFF, num_sampling_steps=steps)
+    import video_llamagen_amd as V
+    keys = ("dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "caption_dim", "vae_embed_dim",
+            "num_frames", "t_downsample_size", "head", "diffloss_w", "diffloss_d", "num_sampling_steps")
+    m = V.Transformer(V.ModelArgs(**{k: cfg[k] for k in keys})).to("cuda", dtype).eval()
+    sd = detweights.gpt_weights(cfg)
+    _, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert set(unexpected) <= {"tok_embeddings.weight", "output.weight"}, unexpected
+    return m, cfg, sd
+
+
+def test_diffloss_head_vs_reference_golden(golden):
+    """gpt_video_diff + DiffLoss.sample: the reference's own generate_video_diff.generate (B=1, cfg 1, 10 sampling steps)."""
+    import video_llamagen_amd as V
+    g = golden("t2vdiff")
+    m, cfg, sd = _diff_model(torch.float32)
+    C, N, S = cfg["vae_embed_dim"], 6, 10
+    noise = cases.rng(51).standard_normal((N, S + 1, 1, C), dtype=np.float32)
+    c, mk = cases.text_cond(1, cfg["cls_token_num"], cfg["caption_dim"], lens=[5])
+    lat = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.9, cfg_iter=1.0, noise=torch.from_numpy(noise))
+    ref = g["t2vdiff_latents"]
+    assert tuple(lat.shape) == ref.shape
+    # fp32: 10 chained network evaluations per token, values O(10): 1e-3 relative to the output range
+    assert np.abs(to_np(lat) - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    # batched semantics (each sample independent) vs the oracle, incl. eager path and lanes
+    B = 3
+    noise = cases.rng(55).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5])
+    om = O.GPTOracle(cfg, sd, "fp32")
+    refb = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=1.0)
+    for graph, lanes in ((True, 1), (False, 1), (True, 2)):
+        m.use_graph, m.lanes = graph, lanes
+        latb = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=1.0, noise=torch.from_numpy(noise))
+        assert np.abs(to_np(latb) - refb).max() < 1e-3 * max(1.0, np.abs(refb).max()), (graph, lanes)
+    m.use_graph, m.lanes = True, 0
+    a = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=11)      # Philox N(0,1) draws
+    b = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=11)
+    d = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=12)
+    assert torch.equal(a, b) and not torch.equal(a, d) and torch.isfinite(a).all()
+    from video_llamagen_amd import _lib
+    with pytest.raises(_lib.VlgError):
+        V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), cfg_iter=2.0)
+
+
+def test_diffloss_head_bf16_and_100_steps():
+    import video_llamagen_amd as V
+    m, cfg, sd = _diff_model(torch.bfloat16, steps=100)
+    C, N, S, B = cfg["vae_embed_dim"], 3, 100, 2
+    noise = cases.rng(57).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 3])
+    lat = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+    om = O.GPTOracle(cfg, sd, "bf16")
+    ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S, dt="bf16"), c, N, mk, noise)
+    # bf16 through 100 chained evaluations: first token within 8e-2 of the oracle's bf16 emulation (later tokens feed back)
+    assert np.isfinite(lat).all()
+    assert np.abs(lat[:, 0] - ref[:, 0]).max() < 8e-2 * max(1.0, np.abs(ref[:, 0]).max())

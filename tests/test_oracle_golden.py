@@ -147,3 +147,32 @@ def test_t2v_adapter2(golden, dt):
     assert lat.shape == ref.shape == (2, N, cfg["vae_embed_dim"])
     tol = 2e-4 if dt == "fp32" else 8e-2
     assert np.abs(lat - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+def test_diffloss_head(golden):
+    """gpt_video_diff + DiffLoss.sample through the reference's generate_video_diff.generate (B = 1, 10 sampling steps)."""
+    g = golden("t2vdiff")
+    sc = O.diffusion_schedule(10)
+    assert (sc["timestep_map"] == g["sched_timestep_map"]).all()
+    np.testing.assert_allclose(sc["sqrt_recip"], g["sched_sqrt_recip"], rtol=1e-12)
+    np.testing.assert_allclose(sc["coef1"], g["sched_coef1"], rtol=1e-12)
+    np.testing.assert_allclose(sc["min_log"], g["sched_min_log"], rtol=1e-12)
+    np.testing.assert_allclose(sc["max_log"], g["sched_max_log"], rtol=1e-12)
+    s100 = O.diffusion_schedule(100)
+    assert (s100["timestep_map"] == g["sched100_timestep_map"]).all()
+    np.testing.assert_allclose(s100["coef2"], g["sched100_coef2"], rtol=1e-12)
+    cfg = cases.TINY_T2V_DIFF
+    sd = detweights.gpt_weights(cfg)
+    head = O.DiffLossOracle(sd, num_sampling_steps=10)
+    C = cfg["vae_embed_dim"]
+    x = cases.rng(52).standard_normal((3, C), dtype=np.float32)
+    z = cases.rng(53).standard_normal((3, cfg["dim"]), dtype=np.float32)
+    np.testing.assert_allclose(head.net(x, np.array([999, 444, 0]), z), g["net_out"], atol=2e-5, rtol=1e-4)
+    m = O.GPTOracle(cfg, sd, "fp32")
+    N, S = 6, 10
+    noise = cases.rng(51).standard_normal((N, S + 1, 1, C), dtype=np.float32)
+    c, mk = cases.text_cond(1, cfg["cls_token_num"], cfg["caption_dim"], lens=[5])
+    lat = O.generate_t2v_diff(m, head, c, N, mk, noise, temperature=0.9)
+    ref = g["t2vdiff_latents"]
+    assert lat.shape == ref.shape == (1, N, C)
+    assert np.abs(lat - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())

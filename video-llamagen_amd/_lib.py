@@ -23,7 +23,8 @@ class GptConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "num_classes",
         "caption_dim", "vae_embed_dim", "num_frames", "t_downsample_size", "head", "dtype", "multiple_of")] + [
-        ("norm_eps", C.c_float), ("rope_base", C.c_float)]
+        ("norm_eps", C.c_float), ("rope_base", C.c_float),
+        ("diffloss_w", C.c_int32), ("diffloss_d", C.c_int32), ("num_sampling_steps", C.c_int32)]
 
 
 class SamplingParams(C.Structure):

@@ -20,6 +20,7 @@ using namespace vlg;
 
 struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
+  DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x;   // DiffLoss head
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
   ~Lane() {
@@ -41,6 +42,12 @@ struct vlg_gpt {
   std::map<std::string, Spec> specs;
   std::map<std::string, Tensor> w;
   DevBuf freqs;
+  // DiffLoss head (VLG_HEAD_HIDDEN)
+  int dW = 0, dDepth = 0, dS = 0;
+  std::vector<DdpmCoef> dcoef;       // per respaced step
+  std::vector<float> dsincos;        // [S][256] timestep embedding inputs
+  DevBuf dtemb;                      // [S][W] time_embed(t) table, handle dtype
+  bool dtemb_ready = false;
 
   // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
   std::vector<std::unique_ptr<Lane>> lanes;
@@ -67,6 +74,70 @@ struct vlg_gpt {
   }
   const void* W(const std::string& n) const { return w.at(n).buf.p; }
 };
+
+// create_diffusion(timestep_respacing=str(n), noise_schedule="cosine", learn_sigma=True): diffusion/__init__.py:11-47,
+// gaussian_diffusion.py:116-150,153-202, respace.py:41-82 - float64 on the host like the reference.
+static void build_diffusion_schedule(int n, std::vector<DdpmCoef>& coef, std::vector<float>& sincos) {
+  const int T = 1000;
+  auto ab = [](double t) {
+    const double c = cos((t + 0.008) / 1.008 * M_PI / 2);
+    return c * c;
+  };
+  std::vector<double> acp(T);
+  double prod = 1.0;
+  for (int i = 0; i < T; ++i) {
+    double beta = 1 - ab((double)(i + 1) / T) / ab((double)i / T);
+    if (beta > 0.999) beta = 0.999;
+    prod *= (1.0 - beta);
+    acp[i] = prod;
+  }
+  std::vector<char> use(T, 0);
+  const double frac = n <= 1 ? 1.0 : (double)(T - 1) / (n - 1);
+  double cur = 0.0;
+  for (int k = 0; k < n; ++k) {
+    use[(int)nearbyint(cur)] = 1;   // Python round(): half to even, as nearbyint in the default rounding mode
+    cur += frac;
+  }
+  std::vector<double> b;
+  std::vector<int> tmap;
+  double last = 1.0;
+  for (int i = 0; i < T; ++i)
+    if (use[i]) {
+      b.push_back(1 - acp[i] / last);
+      last = acp[i];
+      tmap.push_back(i);
+    }
+  const int S = (int)b.size();
+  std::vector<double> ac(S), acprev(S), pv(S);
+  double pr = 1.0;
+  for (int i = 0; i < S; ++i) {
+    acprev[i] = pr;
+    pr *= (1.0 - b[i]);
+    ac[i] = pr;
+    pv[i] = b[i] * (1.0 - acprev[i]) / (1.0 - ac[i]);
+  }
+  coef.resize(S);
+  for (int i = 0; i < S; ++i) {
+    DdpmCoef c;
+    c.sqrt_recip = (float)sqrt(1.0 / ac[i]);
+    c.sqrt_recipm1 = (float)sqrt(1.0 / ac[i] - 1);
+    c.coef1 = (float)(b[i] * sqrt(acprev[i]) / (1.0 - ac[i]));
+    c.coef2 = (float)((1.0 - acprev[i]) * sqrt(1.0 - b[i]) / (1.0 - ac[i]));
+    c.min_log = (float)log(S > 1 ? pv[i == 0 ? 1 : i] : pv[0]);
+    c.max_log = (float)log(b[i]);
+    c.nonzero = i != 0;
+    coef[i] = c;
+  }
+  // TimestepEmbedder.timestep_embedding (diffloss.py:73-91): [cos(t f) | sin(t f)], f = exp(-ln(1e4) k / 128), float math
+  sincos.assign((size_t)S * 256, 0.f);
+  for (int i = 0; i < S; ++i)
+    for (int k = 0; k < 128; ++k) {
+      const float f = expf(-logf(10000.0f) * (float)k / 128.0f);
+      const float a = (float)tmap[i] * f;
+      sincos[(size_t)i * 256 + k] = cosf(a);
+      sincos[(size_t)i * 256 + 128 + k] = sinf(a);
+    }
+}
 
 static int ffn_hidden(int dim, int multiple_of) {
   int hidden = 4 * dim;
@@ -160,6 +231,39 @@ extern "C" int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out) {
     if (cfg->head == VLG_HEAD_ADAPTER2) {
       add("vae_latent_adapter2.fc1.weight", {D, D});
       add("vae_latent_adapter2.fc2.weight", {h->C, D});
+    }
+    if (cfg->head == VLG_HEAD_HIDDEN) {   // diffloss.py:161-190
+      VLG_CHECK(cfg->diffloss_w > 0 && cfg->diffloss_w % 4 == 0 && cfg->diffloss_d > 0 && cfg->num_sampling_steps > 0 &&
+                    cfg->num_sampling_steps <= 1000, VLG_ERR_BAD_ARG, "bad DiffLoss configuration");
+      h->dW = cfg->diffloss_w;
+      h->dDepth = cfg->diffloss_d;
+      const int64_t W = h->dW, dd = h->dDepth, Cc = h->C;
+      const std::string p = "diffloss.net.";
+      auto lin = [&](const std::string& n, int64_t o, int64_t i) {
+        add(p + n + ".weight", {o, i});
+        add(p + n + ".bias", {o});
+      };
+      lin("time_embed.mlp.0", W, 256);
+      lin("time_embed.mlp.2", W, W);
+      lin("cond_embed", W, D);
+      lin("input_proj", W, Cc);
+      lin("final_layer.linear", 2 * Cc, W);
+      const int64_t MR = (3 * dd + 2) * W;
+      for (int64_t b = 0; b < dd; ++b) {
+        const std::string q = p + "res_blocks." + std::to_string(b) + ".";
+        add(q + "in_ln.weight", {W});
+        add(q + "in_ln.bias", {W});
+        add(q + "mlp.0.weight", {W, W});
+        add(q + "mlp.0.bias", {W});
+        add(q + "mlp.2.weight", {W, W});
+        add(q + "mlp.2.bias", {W});
+        add(q + "adaLN_modulation.1.weight", {3 * W, W}, "diffloss.adaln_all.weight", b * 3 * W, {MR, W});
+        add(q + "adaLN_modulation.1.bias", {3 * W}, "diffloss.adaln_all.bias", b * 3 * W, {MR});
+      }
+      add(p + "final_layer.adaLN_modulation.1.weight", {2 * W, W}, "diffloss.adaln_all.weight", dd * 3 * W, {MR, W});
+      add(p + "final_layer.adaLN_modulation.1.bias", {2 * W}, "diffloss.adaln_all.bias", dd * 3 * W, {MR});
+      build_diffusion_schedule(cfg->num_sampling_steps, h->dcoef, h->dsincos);
+      h->dS = (int)h->dcoef.size();
     }
   } else {
     add("tok_embeddings.weight", {V, D});
@@ -341,8 +445,64 @@ struct Runner {
       return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
                                    sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
     }
-    set_error("hidden (diffusion) head is not implemented yet");
-    return VLG_ERR_UNSUPPORTED;
+    return diffloss_head(hl, sp, noise, out_lat, trace);
+  }
+
+  int linear_b(const T* x, const std::string& wname, T* out, int M, int Nn, int K, int act) {
+    int sps = 1;
+    VLG_TRY(gemm_slabs<T>(x, W<T>(wname + ".weight"), ln->ws.as<float>(), M, Nn, K, &sps, st));
+    return reduce_store<T>(ln->ws.as<float>(), sps, out, nullptr, M, Nn, act, st, W<T>(wname + ".bias"));
+  }
+
+  // DiffLoss.sample (diffloss.py:35-52): x_T ~ N(0,1); S reverse steps of {SimpleMLPAdaLN(x, t, c = z) -> p_sample}.
+  // z = hl [B, D] (normed hidden of the last position).  All S steps are enqueued (and graph-captured) back to back.
+  int diffloss_head(const T* z, const vlg_sampling_params& sp, const float* noise, float* out_lat, float* trace) {
+    const int Wd = h->dW, C = h->C, dd = h->dDepth, S = h->dS, MR = (3 * dd + 2) * Wd;
+    const std::string p = "diffloss.net.";
+    T* cemb = ln->d_cemb.as<T>();
+    T* ys = ln->d_ys.as<T>();
+    T* mod = ln->d_mod.as<T>();
+    T* hc = ln->d_h.as<T>();
+    T* g = ln->d_g.as<T>();
+    T* g1 = ln->d_g1.as<T>();
+    T* dout = ln->d_out.as<T>();
+    T* x = ln->d_x.as<T>();
+    VLG_TRY(linear_b(z, p + "cond_embed", cemb, B, Wd, h->D, ACT_NONE));
+    VLG_TRY(dl_init_x<T>(x, noise, state(), S, B, C, b0, Btot, sp.seed, st));
+    for (int k = 0; k < S; ++k) {
+      const int i = S - 1 - k;
+      VLG_TRY(linear_b(x, p + "input_proj", hc, B, Wd, C, ACT_NONE));
+      VLG_TRY(dl_make_y<T>(h->dtemb.as<T>() + (size_t)i * Wd, cemb, ys, B, Wd, st));
+      VLG_TRY(linear_b(ys, "diffloss.adaln_all", mod, B, MR, Wd, ACT_NONE));
+      for (int blk = 0; blk < dd; ++blk) {
+        const std::string q = p + "res_blocks." + std::to_string(blk) + ".";
+        const T* m0 = mod + (size_t)blk * 3 * Wd;   // [shift | scale | gate] (diffloss.py:125)
+        VLG_TRY(dl_ln_modulate<T>(hc, W<T>(q + "in_ln.weight"), W<T>(q + "in_ln.bias"), m0, m0 + Wd, MR, g, B, Wd, st));
+        VLG_TRY(linear_b(g, q + "mlp.0", g1, B, Wd, Wd, ACT_SILU));
+        VLG_TRY(linear_b(g1, q + "mlp.2", g, B, Wd, Wd, ACT_NONE));
+        VLG_TRY(dl_gated_residual<T>(hc, m0 + 2 * Wd, MR, g, B, Wd, st));
+      }
+      const T* mf = mod + (size_t)dd * 3 * Wd;      // [shift | scale] (diffloss.py:145)
+      VLG_TRY(dl_ln_modulate<T>(hc, nullptr, nullptr, mf, mf + Wd, MR, g, B, Wd, st));
+      VLG_TRY(linear_b(g, p + "final_layer.linear", dout, B, 2 * C, Wd, ACT_NONE));
+      VLG_TRY(dl_ddpm_step<T>(x, dout, noise, state(), h->dcoef[i], k, S, B, C, b0, Btot, sp.temperature, sp.seed, st));
+    }
+    return dl_finish<T>(x, ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * C, trace, state(), B, C, N, b0, Btot, st);
+  }
+
+  // time_embed(t) for every respaced step: [S,256] sincos -> Linear -> SiLU -> Linear (diffloss.py:93-96), once per handle
+  int build_time_table() {
+    const int Wd = h->dW, S = h->dS;
+    DevBuf sc, t1;
+    VLG_TRY(sc.reserve((size_t)S * 256 * sizeof(T)));
+    VLG_TRY(t1.reserve((size_t)S * Wd * sizeof(T)));
+    VLG_TRY(upload_convert(sc.p, DT<T>::code, h->dsincos.data(), VLG_F32, 0, (int64_t)S * 256, st));
+    VLG_TRY(h->dtemb.reserve((size_t)S * Wd * sizeof(T)));
+    VLG_TRY(linear_b(sc.as<T>(), "diffloss.net.time_embed.mlp.0", t1.as<T>(), S, Wd, 256, ACT_SILU));
+    VLG_TRY(linear_b(t1.as<T>(), "diffloss.net.time_embed.mlp.2", h->dtemb.as<T>(), S, Wd, Wd, ACT_NONE));
+    VLG_HIP(hipStreamSynchronize(st));
+    h->dtemb_ready = true;
+    return VLG_OK;
   }
 
   int decode_step(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
@@ -401,6 +561,23 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
   need(Bp, h->V > 0 ? h->V : D, D);
   need(Bp, D, h->C > 0 ? h->C : D);
   need(Bp, h->C > 0 ? h->C : D, D);
+  if (h->cfg.head == VLG_HEAD_HIDDEN) {
+    const int Wd = h->dW, MR = (3 * h->dDepth + 2) * Wd;
+    need(Bp, MR, Wd);
+    need(Bp, Wd, D);
+    need(Bp, Wd, h->C);
+    need(Bp, 2 * h->C, Wd);
+    need(h->dS, Wd, 256);
+    need(h->dS, Wd, Wd);
+    VLG_TRY(ln.d_cemb.reserve((size_t)Bp * Wd * e));
+    VLG_TRY(ln.d_ys.reserve((size_t)Bp * Wd * e));
+    VLG_TRY(ln.d_mod.reserve((size_t)Bp * MR * e));
+    VLG_TRY(ln.d_h.reserve((size_t)Bp * Wd * e));
+    VLG_TRY(ln.d_g.reserve((size_t)Bp * Wd * e));
+    VLG_TRY(ln.d_g1.reserve((size_t)Bp * Wd * e));
+    VLG_TRY(ln.d_out.reserve((size_t)Bp * 2 * h->C * e));
+    VLG_TRY(ln.d_x.reserve((size_t)Bp * h->C * e));
+  }
   VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
   VLG_TRY(ln.x.reserve((size_t)M * D * e));
@@ -451,6 +628,10 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     rs.push_back(Runner<T>{h, ln, ln->st, Bl, Bpl, N, S, lo, B, d_mask ? d_mask + (size_t)lo * Tc : nullptr});
   }
   h->last_lanes = nl;
+  if (h->cfg.head == VLG_HEAD_HIDDEN) {
+    VLG_CHECK(!cfg_on, VLG_ERR_UNSUPPORTED, "the DiffLoss head runs with cfg_scale = 1 only (generate_video_diff.py:112-137 never assigns the CFG branch)");
+    if (!h->dtemb_ready) VLG_TRY(rs[0].build_time_table());
+  }
 
   // ---- fork from the caller's stream ----------------------------------------------------------------------------
   VLG_HIP(hipEventRecord(h->ev_in, caller));

@@ -10,7 +10,7 @@ struct StepState {
   int32_t step;   // index of the token being produced (0 = prefill output)
 };
 
-enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1 };
+enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_SILU = 2 };
 
 // ---- GEMM: slabs[s][M][N] (fp32 partial sums over a K slice) = x[M,K] @ w[N,K]^T -----------------
 // returns the number of slabs written through *splits (>= 1).  `ws` must hold max_splits*M*N floats.
@@ -23,8 +23,9 @@ bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_
 size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 
 // out[m][n] = rt(act(rt(sum_s slab[s][m][n])));  out_f32 (optional) receives float(rt(sum)) (gpt.py:371)
+// bias (optional, dtype T, [N]) is added to the fp32 sum before the first rounding (nn.Linear with bias)
 template <typename T>
-int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int N, int act, hipStream_t st);
+int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int N, int act, hipStream_t st, const T* bias = nullptr);
 
 // h[m] = rt(h[m] + rt(sum slabs));  hn[m] = rmsnorm(h[m]) * w      (gpt.py:257-258 + :146-148)
 // if ws == nullptr only the norm is computed (first layer).
@@ -71,6 +72,26 @@ int latent_to_rows(const float* cur, T* out, int B, int Bp, int C, hipStream_t s
 template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp,
                        int C, int N, float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
+
+// ---- DiffLoss head pieces (diffloss.hip) ---------------------------------------------------------------------
+struct DdpmCoef {   // one respaced reverse step (gaussian_diffusion.py:232-252,288-292,334-339)
+  float sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log;
+  int nonzero;      // 0 at t == 0: no noise
+};
+template <typename T>
+int dl_make_y(const T* temb, const T* cemb, T* ys, int B, int W, hipStream_t st);
+template <typename T>
+int dl_ln_modulate(const T* h, const T* lnw, const T* lnb, const T* shift, const T* scale, int mod_stride, T* g, int B, int W, hipStream_t st);
+template <typename T>
+int dl_gated_residual(T* h, const T* gate, int gate_stride, const T* g, int B, int W, hipStream_t st);
+template <typename T>
+int dl_init_x(T* x, const float* noise, const StepState* state, int S, int B, int C, int b_off, int B_total, uint64_t seed, hipStream_t st);
+template <typename T>
+int dl_ddpm_step(T* x, const T* out, const float* noise, const StepState* state, const DdpmCoef& cf, int k, int S, int B, int C, int b_off,
+                 int B_total, float temperature, uint64_t seed, hipStream_t st);
+template <typename T>
+int dl_finish(const T* x, float* cur, float* out_lat, float* trace, const StepState* state, int B, int C, int N, int b_off, int B_total,
+              hipStream_t st);
 
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);

@@ -309,7 +309,8 @@ template int gemm_slabs<bf16>(const bf16*, const bf16*, float*, int, int, int, i
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restrict__ ws, int splits, T* __restrict__ out,
-                                                           float* __restrict__ out_f32, long long MN, int act) {
+                                                           float* __restrict__ out_f32, long long MN, int act, const T* __restrict__ bias,
+                                                           int N) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= MN) return;
   float part[8];
@@ -318,20 +319,22 @@ __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restri
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s += part[k];
+  if (bias) s += DT<T>::ld(bias + i % N);
   s = DT<T>::rt(s);
   if (act == ACT_GELU_TANH) s = DT<T>::rt(gelu_tanh_f(s));
+  if (act == ACT_SILU) s = DT<T>::rt(silu_f(s));
   if (out) DT<T>::st(out + i, s);
   if (out_f32) out_f32[i] = s;
 }
 
 template <typename T>
-int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int N, int act, hipStream_t st) {
+int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int N, int act, hipStream_t st, const T* bias) {
   long long MN = (long long)M * N;
-  reduce_store_kernel<T><<<dim3((unsigned)((MN + 255) / 256)), 256, 0, st>>>(ws, splits, out, out_f32, MN, act);
+  reduce_store_kernel<T><<<dim3((unsigned)((MN + 255) / 256)), 256, 0, st>>>(ws, splits, out, out_f32, MN, act, bias, N);
   return VLG_OK;
 }
-template int reduce_store<float>(const float*, int, float*, float*, int, int, int, hipStream_t);
-template int reduce_store<bf16>(const float*, int, bf16*, float*, int, int, int, hipStream_t);
+template int reduce_store<float>(const float*, int, float*, float*, int, int, int, hipStream_t, const float*);
+template int reduce_store<bf16>(const float*, int, bf16*, float*, int, int, int, hipStream_t, const bf16*);
 
 // NV = 4-element vectors per thread (row = 256 threads x NV x 4 elements): one workgroup per row, the whole row in
 // registers, every split-K slab requested up front (compile-time bound, predicated) with 16-byte loads.

@@ -47,7 +47,9 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
     noise_d = None
     if noise is not None:
         noise_d = noise.to(device=dev, dtype=torch.float32).contiguous()
-        assert tuple(noise_d.shape) == (max_new_tokens, B, model.config.vocab_size)
+        want = (max_new_tokens, B, model.config.vocab_size) if not latent else \
+            (max_new_tokens, int(model.config.num_sampling_steps) + 1, B, model.config.vae_embed_dim)
+        assert tuple(noise_d.shape) == want, (tuple(noise_d.shape), want)
     trace_d = None
     if trace:
         trace_d = torch.empty((max_new_tokens, B, width), dtype=torch.float32, device=dev)
@@ -80,10 +82,14 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
 
 
 @torch.no_grad()
-def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, return_trace=False,
-                 **sampling_kwargs):
-    """Continuous-latent generate (generate_video_diff.py:185-228 skeleton): returns float [B, N, vae_embed_dim]."""
+def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, return_trace=False, noise=None,
+                 cfg_iter=1.0, **sampling_kwargs):
+    """Continuous-latent generate (generate_video_diff.py:185-228): returns float [B, N, vae_embed_dim].
+    head 'adapter2': token = vae_latent_adapter2(h) (gpt_video.py:431); head 'hidden': token = DiffLoss.sample(h, temperature,
+    cfg_iter) (generate_video_diff.py:89-91,132-134) - `noise` [N, steps+1, B, C] N(0,1) draws make it reproducible."""
     if model.model_type != 't2v':
         raise Exception("please check model type")          # generate_video_diff.py:196
-    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, None, return_trace, sampling_kwargs)
+    if cfg_iter != 1.0:
+        raise L.VlgError(-3, "cfg_iter != 1.0 (DiffLoss.forward_with_cfg) is not supported; the reference's scripts run cfg 1")
+    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs)
     return (out, tr) if return_trace else out

@@ -52,7 +52,11 @@ class ModelArgs:
     vae_embed_dim: int = 2048
     t_downsample_size: int = 4
     num_frames: int = 17
-    head: str = 'auto'     # 'logits' | 'adapter2' (gpt_video.py:296,431) | 'hidden' (gpt_video_diff.py:657)
+    head: str = 'auto'     # 'logits' | 'adapter2' (gpt_video.py:296,431) | 'hidden' (gpt_video_diff.py:657 + DiffLoss)
+    # DiffLoss head (gpt_video_diff.py:76-78)
+    diffloss_d: int = 3
+    diffloss_w: int = 1024
+    num_sampling_steps: int = 100
 
 
 class _Embedding:
@@ -148,7 +152,8 @@ class Transformer:
             num_classes=c.num_classes, caption_dim=c.caption_dim if c.model_type != 'c2i' else 0,
             vae_embed_dim=c.vae_embed_dim if c.model_type == 't2v' else 0, num_frames=c.num_frames,
             t_downsample_size=c.t_downsample_size, head=self._head_code(), dtype=L.torch_dtype_code(self._dtype),
-            multiple_of=c.multiple_of, norm_eps=c.norm_eps, rope_base=float(c.rope_base))
+            multiple_of=c.multiple_of, norm_eps=c.norm_eps, rope_base=float(c.rope_base),
+            diffloss_w=c.diffloss_w, diffloss_d=c.diffloss_d, num_sampling_steps=int(c.num_sampling_steps))
         h = C.c_void_p()
         with torch.cuda.device(self._device):
             L.check(L.lib().vlg_gpt_create(C.byref(cfg), C.byref(h)))
@@ -188,6 +193,16 @@ class Transformer:
             if self._head_code() == L.VLG_HEAD_ADAPTER2:
                 out["vae_latent_adapter2.fc1.weight"] = (D, D)
                 out["vae_latent_adapter2.fc2.weight"] = (c.vae_embed_dim, D)
+            if self._head_code() == L.VLG_HEAD_HIDDEN:                       # diffloss.py:161-190
+                Wd, Cc, p = c.diffloss_w, c.vae_embed_dim, "diffloss.net."
+                for n, o, i in (("time_embed.mlp.0", Wd, 256), ("time_embed.mlp.2", Wd, Wd), ("cond_embed", Wd, D), ("input_proj", Wd, Cc),
+                                ("final_layer.adaLN_modulation.1", 2 * Wd, Wd), ("final_layer.linear", 2 * Cc, Wd)):
+                    out[p + n + ".weight"], out[p + n + ".bias"] = (o, i), (o,)
+                for b in range(c.diffloss_d):
+                    q = p + "res_blocks.%d." % b
+                    out[q + "in_ln.weight"], out[q + "in_ln.bias"] = (Wd,), (Wd,)
+                    for n, o in (("mlp.0", Wd), ("mlp.2", Wd), ("adaLN_modulation.1", 3 * Wd)):
+                        out[q + n + ".weight"], out[q + n + ".bias"] = (o, Wd), (o,)
         else:
             out["tok_embeddings.weight"] = (c.vocab_size, D)
             out["output.weight"] = (c.vocab_size, D)
@@ -210,10 +225,14 @@ class Transformer:
         std = self.config.initializer_range if std is None else std
         g = torch.Generator(device=self._device).manual_seed(seed)
         for name, shape in self.param_shapes().items():
-            if name.endswith("norm.weight"):
+            if name.endswith("norm.weight") or name.endswith("in_ln.weight"):
                 t = torch.ones(shape, device=self._device)
             elif name == "cls_embedding.uncond_embedding":
                 t = torch.randn(shape, generator=g, device=self._device) / shape[1] ** 0.5
+            elif name.startswith("diffloss.") and name.endswith(".bias"):
+                t = torch.zeros(shape, device=self._device)
+            elif name.startswith("diffloss.") and len(shape) == 2:
+                t = torch.randn(shape, generator=g, device=self._device) * (0.5 / shape[1] ** 0.5)
             elif name in ("vae_latent_adapter.fc1.weight", "vae_latent_adapter2.fc2.weight"):
                 t = torch.randn(shape, generator=g, device=self._device) * 0.3     # keeps O(1) latents for tiny embed dims
             else:
