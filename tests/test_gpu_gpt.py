@@ -293,6 +293,26 @@ def test_unfused_qkv_path_matches_fused(golden, dt):
     assert d <= (1e-5 if dt == 'fp32' else 0.0), d      # same arithmetic; fp32 may differ by FMA contraction only
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,cfg", [("c2i", cases.TINY_C2I), ("t2i", cases.TINY_T2I)])
+def test_unfused_gemm_path_matches_fused(golden, tag, cfg, dt):
+    """decode uses the fused skinny GEMMs (RMSNorm prologue, residual / RoPE+scatter / SwiGLU epilogues) when the shape allows;
+    the slab GEMM + separate epilogue kernels (always used by prefill, and by shapes like head_dim 100 / D > 2048) must agree."""
+    import video_llamagen_amd as V
+    m, _ = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16)
+    cond, masks = _inputs(cfg)
+    a, ta = V.generate(m, cond, 16, masks, cfg_scale=2.5, cfg_interval=6, sample_logits=False, return_trace=True)
+    m.fuse_gemm = False
+    b, tb = V.generate(m, cond, 16, masks, cfg_scale=2.5, cfg_interval=6, sample_logits=False, return_trace=True)
+    d = (ta - tb).abs().max().item()
+    scale = max(1.0, tb.abs().max().item())
+    # same rounding points; only fp32 summation order differs (split-K slabs vs in-workgroup reduction)
+    assert d <= (2e-5 if dt == "fp32" else 3e-2) * scale, d
+    if dt == "fp32":
+        assert torch.equal(a, b)
+        assert (a.cpu().numpy() == golden("gpt")[f"{tag}_fp32_cfg_ids"]).all()
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_batch_lanes_do_not_change_results(golden, lanes):
     """The batch is split into independent lanes (forked graph branches) purely for overlap: every lane count must

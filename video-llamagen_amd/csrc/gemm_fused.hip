@@ -1,0 +1,342 @@
+// Fused skinny GEMM for the decode step: y = epilogue( prologue(x) @ w^T ), one workgroup per 16-column n-tile, no inter-workgroup
+// split-K (so the epilogue can finish the op in place) - removes the RMSNorm, RoPE/KV-scatter, SiLU*mul and residual kernels
+// and all fp32 slab traffic from the decode layer (9 -> 6 launches per layer).
+//
+//   prologue  PRO_NORM : x is the residual stream h [M,K]; every workgroup holds the full K range of its rows in registers
+//                        (it needs them as the A operand anyway), so it computes sum(h^2) itself (wave partials -> LDS), then
+//                        normalises its fragments in registers: rt(rt(h * rsqrt(mean + eps)) * g)   (gpt.py:143-148, exact
+//                        rounding order of the reference).  No extra memory traffic.
+//   epilogues EPI_RESID  h[row][col] = rt(h + rt(acc))                                    (gpt.py:257-258)
+//             EPI_QKV    RoPE on adjacent pairs (partner column sits in the neighbouring thread's LDS slot) + scatter to the
+//                        q buffer / KV cache at position p                                    (gpt.py:215-227,182-183)
+//             EPI_SWIGLU n-tile taken from both halves of [w1; w3]: g = rt(rt(silu(rt(a))) * rt(b))   (gpt.py:167)
+//             EPI_STORE  out = rt(act(rt(acc + bias))) (T and/or fp32)                        (heads, adapters)
+#include "gpt_kernels.h"
+
+namespace vlg {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float silu_g(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_g(float x) {
+  const float k = 0.7978845608028654f;
+  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {   // two RNE bf16 in one v_cvt_pk_bf16_f32
+  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <typename T>
+struct KB;
+template <>
+struct KB<bf16> { static constexpr int KBLK = 128; };
+template <>
+struct KB<float> { static constexpr int KBLK = 64; };
+
+template <typename T>
+__device__ __forceinline__ float sumsq(const u32x4_t& v) {
+  float s = 0.f;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = lo16(v[j]), b = hi16(v[j]);
+      s += a * a + b * b;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = __uint_as_float(v[j]);
+      s += a * a;
+    }
+  }
+  return s;
+}
+
+// v <- rt(rt(v * rs) * g)
+template <typename T>
+__device__ __forceinline__ void norm_frag(u32x4_t& v, float rs, const u32x4_t& g) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t n = pack2(lo16(v[j]) * rs, hi16(v[j]) * rs);
+      v[j] = pack2(lo16(n) * lo16(g[j]), hi16(n) * hi16(g[j]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(__uint_as_float(v[j]) * rs * __uint_as_float(g[j]));
+  }
+}
+
+template <typename T, int MT>
+__device__ __forceinline__ void mfma_blk(const u32x4_t (&a)[MT][4], const u32x4_t (&b)[4], f32x4_t (&acc)[MT]) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8_t vb = __builtin_bit_cast(bf16x8_t, b[s]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[mt][s]), vb, acc[mt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[mt][s][e]), __uint_as_float(b[s][e]), acc[mt], 0, 0, 0);
+  }
+}
+
+template <typename T, int MT, int NW, bool PRO, int EPI>
+__global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, FusedGemm fa) {
+  constexpr int KBLK = KB<T>::KBLK;
+  constexpr int NH = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int NB = (MT * NH >= 4) ? 2 : 4;
+  constexpr int EPV = 16 / sizeof(T);   // elements per 16-byte vector
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
+  const int nkb = K / KBLK;
+
+  __shared__ float red[NW][NH][MT][256];
+  __shared__ float ssq_sm[NW][MT * 16];
+  __shared__ u32x4_t gsm[PRO ? 256 : 1];   // norm weight, K * sizeof(T) <= 4 KiB
+
+  f32x4_t acc[NH][MT];
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[hf][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const T* wrow[NH];
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) wrow[hf] = w + (size_t)(n0 + r + (NH == 2 ? hf * N : 0)) * K;
+  const T* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = m0 + mt * 16 + r;
+    row = row < M ? row : M - 1;
+    xrow[mt] = x + (size_t)row * K;
+  }
+  if constexpr (PRO) {
+    const int nvec = K / EPV;
+    if ((int)threadIdx.x < nvec) gsm[threadIdx.x] = reinterpret_cast<const u32x4_t*>(fa.norm_w)[threadIdx.x];
+  }
+
+  u32x4_t a[NB][MT][4], b[NB][NH][4];
+  for (int kb0 = wave; kb0 < nkb; kb0 += NB * NW) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kb = kb0 + i * NW;
+      if (kb < nkb) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+          const u32x4_t* pw = reinterpret_cast<const u32x4_t*>(wrow[hf] + (size_t)kb * KBLK) + q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) b[i][hf][s2] = __builtin_nontemporal_load(pw + s2 * 4);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK) + q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * 4];
+        }
+      }
+    }
+    if constexpr (PRO) {
+      // host guarantees nkb <= NB * NW: this loop body runs once per wave and holds all of the rows' K range
+      float part[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          if (kb0 + i * NW < nkb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) p += sumsq<T>(a[i][mt][s2]);
+          }
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        part[mt] = p;
+      }
+      if (q == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ssq_sm[wave][mt * 16 + r] = part[mt];
+      }
+    }
+    if constexpr (PRO) {
+      // waves without K blocks never enter this loop: they publish zeros below, outside it
+    }
+    if constexpr (!PRO) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (kb0 + i * NW < nkb) {
+#pragma unroll
+          for (int hf = 0; hf < NH; ++hf) mfma_blk<T, MT>(a[i], b[i][hf], acc[hf]);
+        }
+    }
+  }
+  if constexpr (PRO) {
+    if (wave >= nkb && q == 0) {   // this wave owns no K block
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) ssq_sm[wave][mt * 16 + r] = 0.f;
+    }
+    __syncthreads();
+    if (wave < nkb) {
+      float rs[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) tot += ssq_sm[wv][mt * 16 + r];
+        rs[mt] = 1.0f / sqrtf(tot / (float)K + fa.eps);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kb = wave + i * NW;
+        if (kb < nkb) {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const u32x4_t g = gsm[kb * (KBLK / EPV) + s2 * 4 + q];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) norm_frag<T>(a[i][mt][s2], rs[mt], g);
+          }
+#pragma unroll
+          for (int hf = 0; hf < NH; ++hf) mfma_blk<T, MT>(a[i], b[i][hf], acc[hf]);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction ----
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][hf][mt][e * 64 + lane] = acc[hf][mt][e];
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= 256) return;
+  const int e = t >> 6, l2 = t & 63;
+  const int col = n0 + (l2 & 15);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
+    float s0 = 0.f, s1 = 0.f, sp = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) {
+      s0 += red[wv][0][mt][t];
+      if constexpr (NH == 2) s1 += red[wv][1][mt][t];
+      if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
+    }
+    if (row >= M) continue;
+    if constexpr (EPI == EPI_RESID) {
+      T* hp = reinterpret_cast<T*>(fa.h) + (size_t)row * N + col;
+      DT<T>::st(hp, DT<T>::ld(hp) + DT<T>::rt(s0));
+    } else if constexpr (EPI == EPI_SWIGLU) {
+      const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
+      DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, DT<T>::rt(silu_g(av)) * bv);
+    } else if constexpr (EPI == EPI_STORE) {
+      float v = s0;
+      if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
+      v = DT<T>::rt(v);
+      if (fa.act == ACT_GELU_TANH) v = DT<T>::rt(gelu_g(v));
+      if (fa.act == ACT_SILU) v = DT<T>::rt(silu_g(v));
+      if (fa.out) DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, v);
+      if (fa.out_f32) fa.out_f32[(size_t)row * N + col] = v;
+    } else {  // EPI_QKV
+      const int D = fa.H * fa.hd;
+      const int sec = col / D, within = col - sec * D;
+      const int hh = within / fa.hd, d = within - hh * fa.hd;
+      const int bq = row / fa.Tq, tq = row - bq * fa.Tq;
+      const int p = fa.state->pos + tq;
+      const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
+      float o = xs;
+      if (sec < 2) {
+        const float2 cs = *reinterpret_cast<const float2*>(fa.freqs + ((size_t)p * (fa.hd / 2) + d / 2) * 2);
+        o = (d & 1) ? __fadd_rn(__fmul_rn(xs, cs.x), __fmul_rn(xp, cs.y))    // x1*c + x0*s
+                    : __fsub_rn(__fmul_rn(xs, cs.x), __fmul_rn(xp, cs.y));   // x0*c - x1*s
+      }
+      T* dst;
+      if (sec == 0)
+        dst = reinterpret_cast<T*>(fa.qbuf) + ((size_t)row * fa.H + hh) * fa.hd + d;
+      else
+        dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + (((size_t)bq * fa.H + hh) * fa.S + p) * fa.hd + d;
+      DT<T>::st(dst, o);
+    }
+  }
+}
+
+template <typename T, int MT, int NW, bool PRO>
+void launch_epi(int epi, dim3 grid, hipStream_t st, const T* x, const T* w, int M, int N, int K, const FusedGemm& fa) {
+  switch (epi) {
+    case EPI_RESID: gemm_fused_kernel<T, MT, NW, PRO, EPI_RESID><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
+    case EPI_QKV: gemm_fused_kernel<T, MT, NW, PRO, EPI_QKV><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
+    case EPI_SWIGLU: gemm_fused_kernel<T, MT, NW, PRO, EPI_SWIGLU><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
+    default: gemm_fused_kernel<T, MT, NW, PRO, EPI_STORE><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
+  }
+}
+
+}  // namespace
+
+// true if the fused kernel covers this shape (otherwise the caller uses the slab GEMM + separate epilogue kernels)
+template <typename T>
+bool gemm_fused_ok(int M, int N, int K, bool pro, int epi) {
+  constexpr int KBLK = KB<T>::KBLK;
+  if (M < 1 || K % KBLK != 0 || N % 16 != 0) return false;
+  if (!pro) return true;
+  const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
+  const int nh = epi == EPI_SWIGLU ? 2 : 1;
+  const int nb = (mt * nh >= 4) ? 2 : 4;
+  const int nw = (nb == 2) ? 8 : 4;
+  return K / KBLK <= nb * nw && (size_t)K * sizeof(T) <= 4096;
+}
+template bool gemm_fused_ok<float>(int, int, int, bool, int);
+template bool gemm_fused_ok<bf16>(int, int, int, bool, int);
+
+template <typename T>
+int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st) {
+  if (!gemm_fused_ok<T>(M, N, K, pro, epi)) {
+    set_error("gemm_fused: shape M=%d N=%d K=%d pro=%d epi=%d not covered", M, N, K, (int)pro, epi);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
+  const int nh = epi == EPI_SWIGLU ? 2 : 1;
+  const bool wide = (mt * nh >= 4);   // NB = 2 -> 8 waves so a workgroup still covers 16 K blocks
+  dim3 grid(N / 16, cdiv(M, mt * 16), 1);
+#define VLG_GF(MT_, NW_)                                                            \
+  do {                                                                              \
+    if (pro)                                                                        \
+      launch_epi<T, MT_, NW_, true>(epi, grid, st, x, w, M, N, K, fa);              \
+    else                                                                            \
+      launch_epi<T, MT_, NW_, false>(epi, grid, st, x, w, M, N, K, fa);             \
+  } while (0)
+  if (mt == 4)
+    VLG_GF(4, 8);
+  else if (mt == 2) {
+    if (wide)
+      VLG_GF(2, 8);
+    else
+      VLG_GF(2, 4);
+  } else {
+    VLG_GF(1, 4);
+  }
+#undef VLG_GF
+  return VLG_OK;
+}
+template int gemm_fused<float>(const float*, const float*, int, int, int, bool, int, const FusedGemm&, hipStream_t);
+template int gemm_fused<bf16>(const bf16*, const bf16*, int, int, int, bool, int, const FusedGemm&, hipStream_t);
+
+}  // namespace vlg

@@ -56,6 +56,7 @@ struct vlg_gpt {
   hipStream_t s_int = nullptr;   // weight uploads
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
   bool use_graph = true;
+  bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
   bool fuse_qkv = false;             // decode: RoPE + KV append inside the attention kernel (r01: +4 us/layer vs the separate
                                      // scatter kernel - 111 VGPRs and a dependent prologue - so off by default)
@@ -336,6 +337,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->time_attn = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "fuse_gemm")) {
+    h->fuse_gemm = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "fuse_swiglu")) {
     h->fuse_swiglu = value != 0;
     return VLG_OK;
@@ -431,6 +436,87 @@ struct Runner {
     return VLG_OK;
   }
 
+  // ---- fused decode path (Tq == 1): 6 launches per layer, no slabs ------------------------------------------------------
+  bool fused_decode_ok() {
+    const int D = h->D, F = h->F;
+    if (!h->fuse_gemm || h->hd % 2 != 0) return false;
+    bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_fused_ok<T>(Bp, D, D, false, EPI_RESID) &&
+              gemm_fused_ok<T>(Bp, F, D, true, EPI_SWIGLU) && gemm_fused_ok<T>(Bp, D, F, false, EPI_RESID);
+    if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, true, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_ADAPTER2) ok = ok && gemm_fused_ok<T>(Bp, D, D, true, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, true, EPI_STORE);
+    return ok;
+  }
+
+  // x [Bp, D] = residual stream (token / latent embeddings); on return x holds the last layer's output, NOT normed
+  int layers_fused() {
+    const int M = Bp, D = h->D, H = h->H, hd = h->hd, F = h->F;
+    T* x = ln->x.as<T>();
+    const size_t lstride = (size_t)Bp * H * S * hd;
+    for (int l = 0; l < h->L; ++l) {
+      const std::string p = "layers." + std::to_string(l) + ".";
+      T* kc = ln->kcache.as<T>() + lstride * l;
+      T* vc = ln->vcache.as<T>() + lstride * l;
+      FusedGemm fa;
+      fa.norm_w = W<T>(p + "attention_norm.weight");
+      fa.eps = h->cfg.norm_eps;
+      fa.qbuf = ln->q.as<T>();
+      fa.kc = kc;
+      fa.vc = vc;
+      fa.freqs = h->freqs.as<float>();
+      fa.state = state();
+      fa.Tq = 1;
+      fa.H = H;
+      fa.hd = hd;
+      fa.S = S;
+      VLG_TRY(gemm_fused<T>(x, W<T>(p + "attention.wqkv.weight"), M, 3 * D, D, true, EPI_QKV, fa, st));
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (l == 0 && ev_slot >= 0) {
+        e0 = h->attn_ev[2 * ev_slot];
+        e1 = h->attn_ev[2 * ev_slot + 1];
+      }
+      VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
+                           st, e0, e1));
+      FusedGemm fr;
+      fr.h = x;
+      VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
+      FusedGemm fs;
+      fs.norm_w = W<T>(p + "ffn_norm.weight");
+      fs.eps = h->cfg.norm_eps;
+      fs.out = ln->g.as<T>();
+      VLG_TRY(gemm_fused<T>(x, W<T>(p + "feed_forward.w13"), M, F, D, true, EPI_SWIGLU, fs, st));
+      VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
+    }
+    return VLG_OK;
+  }
+
+  // head on the un-normed residual stream x [Bp, D]: the final RMSNorm (gpt.py:370) is the head GEMM's prologue
+  int head_fused(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
+    const int D = h->D;
+    FusedGemm fa;
+    fa.norm_w = W<T>("norm.weight");
+    fa.eps = h->cfg.norm_eps;
+    if (h->cfg.head == VLG_HEAD_LOGITS) {
+      fa.out_f32 = ln->logits.as<float>();
+      VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("output.weight"), Bp, h->V, D, true, EPI_STORE, fa, st));
+      return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
+                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot);
+    }
+    if (h->cfg.head == VLG_HEAD_ADAPTER2) {
+      fa.out = ln->t1.as<T>();
+      fa.act = ACT_GELU_TANH;
+      VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("vae_latent_adapter2.fc1.weight"), Bp, D, D, true, EPI_STORE, fa, st));
+      VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter2.fc2.weight", ln->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
+      return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
+                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
+    }
+    // hidden (DiffLoss): cond_embed(norm(x)) is the first op of the head (diffloss.py:227)
+    fa.out = ln->d_cemb.as<T>();
+    fa.bias = W<T>("diffloss.net.cond_embed.bias");
+    VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("diffloss.net.cond_embed.weight"), Bp, h->dW, D, true, EPI_STORE, fa, st));
+    return diffloss_head(nullptr, sp, noise, out_lat, trace);
+  }
+
   // hl [Bp, D] (normed hidden of the last position) -> sampled token / latent for state->step
   int head(const T* hl, const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
@@ -467,7 +553,7 @@ struct Runner {
     T* g1 = ln->d_g1.as<T>();
     T* dout = ln->d_out.as<T>();
     T* x = ln->d_x.as<T>();
-    VLG_TRY(linear_b(z, p + "cond_embed", cemb, B, Wd, h->D, ACT_NONE));
+    if (z) VLG_TRY(linear_b(z, p + "cond_embed", cemb, B, Wd, h->D, ACT_NONE));   // else: already produced by head_fused
     VLG_TRY(dl_init_x<T>(x, noise, state(), S, B, C, b0, Btot, sp.seed, st));
     for (int k = 0; k < S; ++k) {
       const int i = S - 1 - k;
@@ -514,8 +600,13 @@ struct Runner {
     } else {
       VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st));
     }
-    VLG_TRY(layers(1, S - 1));
-    VLG_TRY(head(ln->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
+    if (fused_decode_ok()) {
+      VLG_TRY(layers_fused());
+      VLG_TRY(head_fused(sp, noise, out_ids, out_lat, trace));
+    } else {
+      VLG_TRY(layers(1, S - 1));
+      VLG_TRY(head(ln->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
+    }
     return advance_state(state(), st);
   }
 

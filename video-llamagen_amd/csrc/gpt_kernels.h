@@ -22,6 +22,28 @@ template <typename T>
 bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_t st);
 size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 
+// ---- fused skinny GEMM (gemm_fused.hip): prologue RMSNorm + epilogue residual / RoPE+scatter / SwiGLU / store -------------
+enum FusedEpi { EPI_RESID = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_STORE = 3 };
+struct FusedGemm {
+  const void* norm_w = nullptr;   // PRO: RMSNorm weight [K] (dtype T)
+  float eps = 1e-5f;
+  void* h = nullptr;              // EPI_RESID: residual stream [M,N], updated in place
+  void* qbuf = nullptr;           // EPI_QKV: q [M,H,hd]; caches [Bp,H,S,hd]
+  void* kc = nullptr;
+  void* vc = nullptr;
+  const float* freqs = nullptr;
+  const StepState* state = nullptr;
+  int Tq = 1, H = 0, hd = 0, S = 0;
+  void* out = nullptr;            // EPI_SWIGLU: g [M,N]; EPI_STORE: out [M,N] (T)
+  float* out_f32 = nullptr;       // EPI_STORE
+  const void* bias = nullptr;     // EPI_STORE (dtype T)
+  int act = 0;
+};
+template <typename T>
+bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
+template <typename T>
+int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st);
+
 // out[m][n] = rt(act(rt(sum_s slab[s][m][n])));  out_f32 (optional) receives float(rt(sum)) (gpt.py:371)
 // bias (optional, dtype T, [N]) is added to the fp32 sum before the first rounding (nn.Linear with bias)
 template <typename T>

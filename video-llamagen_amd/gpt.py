@@ -110,6 +110,7 @@ class Transformer:
         self._loaded = set()
         self.use_graph = True
         self.time_attn = False
+        self.fuse_gemm = True    # decode: fused skinny GEMMs (norm prologue, residual / RoPE+scatter / SwiGLU epilogues)
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
         self.fuse_qkv = False    # decode: RoPE + KV append fused into the attention kernel
         self.lanes = 0          # 0 = auto: independent batch lanes on forked graph branches (see csrc/gpt.hip)
