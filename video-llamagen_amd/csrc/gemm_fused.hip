@@ -108,8 +108,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   const int r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
   const int nkb = K / KBLK;
+  const int split = blockIdx.z, splits = gridDim.z;   // > 1 only for !PRO kernels (host-enforced)
 
   __shared__ float red[NW][NH][MT][256];
+  __shared__ int ticket_sm;
   __shared__ float ssq_sm[NW][MT * 16];
   __shared__ u32x4_t gsm[PRO ? 256 : 1];   // norm weight, K * sizeof(T) <= 4 KiB
 
@@ -135,10 +137,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   }
 
   u32x4_t a[NB][MT][4], b[NB][NH][4];
-  for (int kb0 = wave; kb0 < nkb; kb0 += NB * NW) {
+  const int kstride = NW * splits;
+  for (int kb0 = split * NW + wave; kb0 < nkb; kb0 += NB * kstride) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int kb = kb0 + i * NW;
+      const int kb = kb0 + i * kstride;
       if (kb < nkb) {
 #pragma unroll
         for (int hf = 0; hf < NH; ++hf) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
         float p = 0.f;
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-          if (kb0 + i * NW < nkb) {
+          if (kb0 + i * kstride < nkb) {
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) p += sumsq<T>(a[i][mt][s2]);
           }
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     if constexpr (!PRO) {
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        if (kb0 + i * NW < nkb) {
+        if (kb0 + i * kstride < nkb) {
 #pragma unroll
           for (int hf = 0; hf < NH; ++hf) mfma_blk<T, MT>(a[i], b[i][hf], acc[hf]);
         }
@@ -228,18 +231,65 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       for (int e = 0; e < 4; ++e) red[wave][hf][mt][e * 64 + lane] = acc[hf][mt][e];
   __syncthreads();
   const int t = threadIdx.x;
-  if (t >= 256) return;
   const int e = t >> 6, l2 = t & 63;
   const int col = n0 + (l2 & 15);
+  float part[MT];
+  if constexpr (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE)) {
+    if (splits > 1) {
+      // In-launch split-K combine (cdna_hip_programming.md §5 "In-launch split-K reduction"): every K-slice workgroup writes
+      // its fp32 tile, releases at agent scope, takes a ticket; the last arriver acquires, sums the slices in slice order
+      // (deterministic) and runs the epilogue.  The counter is reset by the last arriver (zeroed once at allocation).
+      const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+      float* slab = fa.slabs + ((size_t)tile * splits + split) * (MT * 256);
+      if (t < 256) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) v += red[wv][0][mt][t];
+          slab[mt * 256 + t] = v;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket_sm = __hip_atomic_fetch_add(fa.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (ticket_sm != splits - 1) return;
+      if (t == 0) {
+        __hip_atomic_store(fa.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (t < 256) {
+        const float* base = fa.slabs + (size_t)tile * splits * (MT * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v = 0.f;
+          for (int sp2 = 0; sp2 < splits; ++sp2) v += base[(size_t)sp2 * (MT * 256) + mt * 256 + t];
+          part[mt] = v;
+        }
+      }
+    }
+  }
+  if (t >= 256) return;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
     float s0 = 0.f, s1 = 0.f, sp = 0.f;
+    if (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE) && splits > 1) {
+      s0 = part[mt];
+    } else {
 #pragma unroll
-    for (int wv = 0; wv < NW; ++wv) {
-      s0 += red[wv][0][mt][t];
-      if constexpr (NH == 2) s1 += red[wv][1][mt][t];
-      if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
+      for (int wv = 0; wv < NW; ++wv) {
+        s0 += red[wv][0][mt][t];
+        if constexpr (NH == 2) s1 += red[wv][1][mt][t];
+        if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
+      }
     }
     if (row >= M) continue;
     if constexpr (EPI == EPI_RESID) {
@@ -315,7 +365,20 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
   const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   const int nh = epi == EPI_SWIGLU ? 2 : 1;
   const bool wide = (mt * nh >= 4);   // NB = 2 -> 8 waves so a workgroup still covers 16 K blocks
-  dim3 grid(N / 16, cdiv(M, mt * 16), 1);
+  int splits = 1;
+  if (!pro && (epi == EPI_RESID || epi == EPI_STORE) && fa.slabs && fa.counters) {
+    // few n-tiles (N = D): split K over workgroups so every CU streams weights; combined in-launch by the last arriver
+    const int tiles = (N / 16) * cdiv(M, mt * 16);
+    const int nw = (mt == 4 || wide) ? 8 : 4;
+    const int nkb = K / KB<T>::KBLK;
+    splits = (240 + tiles / 2) / tiles;
+    const int maxs = (nkb + nw - 1) / nw;
+    if (splits > maxs) splits = maxs;
+    if (splits > 8) splits = 8;
+    if (splits < 1) splits = 1;
+    if (tiles > fa.max_tiles) splits = 1;
+  }
+  dim3 grid(N / 16, cdiv(M, mt * 16), splits);
 #define VLG_GF(MT_, NW_)                                                            \
   do {                                                                              \
     if (pro)                                                                        \

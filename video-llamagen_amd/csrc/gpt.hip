@@ -21,6 +21,7 @@ using namespace vlg;
 struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x;   // DiffLoss head
+  DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
   ~Lane() {
@@ -56,6 +57,7 @@ struct vlg_gpt {
   hipStream_t s_int = nullptr;   // weight uploads
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
   bool use_graph = true;
+  bool splitk_inlaunch = false;      // residual GEMMs: K split over workgroups, combined in-launch by the last arriver
   bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
   bool fuse_qkv = false;             // decode: RoPE + KV append inside the attention kernel (r01: +4 us/layer vs the separate
@@ -337,6 +339,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->time_attn = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "splitk_inlaunch")) {
+    h->splitk_inlaunch = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "fuse_gemm")) {
     h->fuse_gemm = value != 0;
     return VLG_OK;
@@ -375,6 +381,8 @@ extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* 
 }
 
 namespace {
+
+constexpr int kMaxTiles = 4096;   // arrival counters per lane for the in-launch split-K GEMMs
 
 // One lane = an independent slice of the batch with its own activations, KV cache, step state and stream.
 // Lanes share the weights.  Two lanes on forked graph branches let one lane's latency-bound kernels (skinny GEMMs,
@@ -479,6 +487,11 @@ struct Runner {
                            st, e0, e1));
       FusedGemm fr;
       fr.h = x;
+      if (h->splitk_inlaunch) {   // measured r01: the release/acquire pair costs more than the idle CUs (22.9 s vs 22.6 s/step)
+        fr.slabs = ln->ws.as<float>();
+        fr.counters = ln->counters.as<int>();
+        fr.max_tiles = kMaxTiles;
+      }
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
       fs.norm_w = W<T>(p + "ffn_norm.weight");
@@ -687,6 +700,13 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
   if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
   VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
   VLG_TRY(ln.state.reserve(sizeof(StepState)));
+  if (ln.counters.bytes == 0) {
+    VLG_TRY(ln.counters.reserve(kMaxTiles * sizeof(int)));
+    VLG_HIP(hipMemset(ln.counters.p, 0, kMaxTiles * sizeof(int)));
+  }
+  // fused split-K tile slabs live in ws: tiles * splits * MT*256 floats <= 8 * (Bp rounded to 64) * N
+  wsf = std::max(wsf, (size_t)8 * (size_t)round_up(Bp, 64) * (size_t)std::max(D, F));
+  VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   if (!ln.st) VLG_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
   if (!ln.ev) VLG_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
   return VLG_OK;

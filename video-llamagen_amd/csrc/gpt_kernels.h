@@ -38,6 +38,11 @@ struct FusedGemm {
   float* out_f32 = nullptr;       // EPI_STORE
   const void* bias = nullptr;     // EPI_STORE (dtype T)
   int act = 0;
+  // optional in-launch split-K (EPI_RESID / EPI_STORE without prologue): fp32 tile slabs [tiles][splits][MT*256] and one
+  // arrival counter per tile (zero at allocation; the last arriver resets it)
+  float* slabs = nullptr;
+  int* counters = nullptr;
+  int max_tiles = 0;
 };
 template <typename T>
 bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
