@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libvlg.so is built in-tree (hipcc, gfx950) if it is missing or older than its sources; the tests never fall back."""
+    import video_llamagen_amd  # noqa: F401
+    from video_llamagen_amd import build
+    build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
