@@ -153,6 +153,24 @@ int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, in
                         int32_t* d_idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * tokenizer_video VQ-VAE decode   replaces VQVAE.decode tokenizer/tokenizer_video/vqvae.py:48-51 (+ Decoder :245-272,
+ *                                 AttentionResidualBlock/AxialBlock :89-125, SamePadConv(Transpose)3d :276-319)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlg_vqvae vlg_vqvae_t;
+typedef struct {
+  int32_t n_hiddens, embedding_dim, n_codes, n_res_layers, n_head; /* vqvae.py:78-86 (240, 256, 2048, 4; AxialBlock n_head 2) */
+  int32_t n_upsample;                                              /* transposed 4^3 stride-2 convs (downsample (4,4,4) -> 2)    */
+  int32_t dtype;
+} vlg_vqvae_config;
+int vlg_vqvae_create(const vlg_vqvae_config* cfg, vlg_vqvae_t** out);
+int vlg_vqvae_destroy(vlg_vqvae_t* h);
+int vlg_vqvae_load_tensor(vlg_vqvae_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                          int32_t src_dtype, int32_t src_on_device, int32_t* consumed);
+/* d_codes int32 [B, t, h, w] -> d_out fp32 [B, 3, t*2^n_up, h*2^n_up, w*2^n_up] */
+int vlg_vqvae_decode(vlg_vqvae_t* h, const int32_t* d_codes, int32_t B, int32_t t, int32_t hh, int32_t ww, float* d_out,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * CausalVideoVAE decoder   replaces CausalVAEModel.decode modeling_causalvae.py:394-404
  * ------------------------------------------------------------------------------------------ */
 typedef struct vlg_vae vlg_vae_t;

@@ -26,6 +26,7 @@ GPT_SIZES = {  # gpt.py:441-464
     "GPT-3B": dict(n_layer=24, n_head=32, dim=3200), "GPT-7B": dict(n_layer=32, n_head=32, dim=4096),
 }
 
+TINY_VIDEOVQ = dict(n_hiddens=48, embedding_dim=32, n_codes=64, n_res_layers=2, n_upsample=2)
 TINY_VAE = dict(hidden_size=32, hidden_size_mult=(1, 2, 4, 4), z_channels=4, embed_dim=8, num_res_blocks=2)
 
 

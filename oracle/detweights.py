@@ -197,3 +197,42 @@ def vae_weights(cfg=None, seed=1234):
     _gn(sd, "decoder.norm_out", block_in, seed)
     _conv(sd, "decoder.conv_out.conv", 3, block_in, 3, seed, nd=3)
     return sd
+
+
+def videovq_weights(cfg=None, seed=1234):
+    """tokenizer_video VQVAE decode side (vqvae.py:17-31,89-125,245-272): codebook, post_vq_conv, decoder."""
+    cfg = dict(cfg or {})
+    nh = cfg.get("n_hiddens", 240)
+    ed = cfg.get("embedding_dim", 256)
+    nc = cfg.get("n_codes", 2048)
+    nres = cfg.get("n_res_layers", 4)
+    n_up = cfg.get("n_upsample", 2)
+    sd = {}
+    sd["codebook.embeddings"] = normal("codebook.embeddings", (nc, ed), 1.0, seed)
+    _conv(sd, "post_vq_conv.conv", nh, ed, 1, seed, nd=3)
+
+    def bn(name, c):
+        sd[name + ".weight"] = (1.0 + normal(name + ".weight", (c,), 0.1, seed)).astype(np.float32)
+        sd[name + ".bias"] = normal(name + ".bias", (c,), 0.05, seed)
+        sd[name + ".running_mean"] = normal(name + ".running_mean", (c,), 0.1, seed)
+        sd[name + ".running_var"] = (1.0 + np.abs(normal(name + ".running_var", (c,), 0.2, seed))).astype(np.float32)
+
+    for i in range(nres):
+        p = f"decoder.res_stack.{i}.block."
+        bn(p + "0", nh)
+        sd[p + "2.conv.weight"] = normal(p + "2.conv.weight", (nh // 2, nh, 3, 3, 3), 1.0 / np.sqrt(nh * 27), seed)
+        bn(p + "3", nh // 2)
+        sd[p + "5.conv.weight"] = normal(p + "5.conv.weight", (nh, nh // 2, 1, 1, 1), 1.0 / np.sqrt(nh // 2), seed)
+        bn(p + "6", nh)
+        for ax in ("attn_w", "attn_h", "attn_t"):
+            q = p + "8." + ax + "."
+            for n in ("w_qs", "w_ks", "w_vs"):
+                sd[q + n + ".weight"] = normal(q + n + ".weight", (nh, nh), 1.0 / np.sqrt(nh), seed)
+            sd[q + "fc.weight"] = normal(q + "fc.weight", (nh, nh), 0.5 / np.sqrt(nh), seed)
+            sd[q + "fc.bias"] = normal(q + "fc.bias", (nh,), 0.02, seed)
+    bn(f"decoder.res_stack.{nres}", nh)
+    for i in range(n_up):
+        co = 3 if i == n_up - 1 else nh
+        sd[f"decoder.convts.{i}.convt.weight"] = normal(f"decoder.convts.{i}.convt.weight", (nh, co, 4, 4, 4), 1.0 / np.sqrt(nh * 8), seed)
+        sd[f"decoder.convts.{i}.convt.bias"] = normal(f"decoder.convts.{i}.convt.bias", (co,), 0.02, seed)
+    return sd

@@ -93,3 +93,40 @@ def load_vae_decoder_cls():
               resolve_str_to_obj=mu.resolve_str_to_obj)
     exec(code, ns)
     return ns["Decoder"], mods
+
+
+def load_videovq_classes():
+    """tokenizer/tokenizer_video/vqvae.py imports pytorch_lightning (absent): AST-extract the decode-side classes and exec
+    them with the (importable) attention/utils helpers in scope."""
+    _install()
+    import importlib.util
+    import math
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    base = os.path.join(REF, "tokenizer/tokenizer_video")
+
+    def load_file(name):
+        spec = importlib.util.spec_from_file_location("ref_tv_" + name, os.path.join(base, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        return spec, mod
+
+    ut_src = open(os.path.join(base, "utils.py")).read()
+    ns_ut = {}
+    tree = ast.parse(ut_src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("shift_dim", "view_range", "tensor_slice")]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "utils.py", "exec"), ns_ut)
+    at_src = open(os.path.join(base, "attention.py")).read()
+    tree = ast.parse(at_src)
+    keep = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name in ("MultiHeadAttention", "AxialAttention", "FullAttention"))
+            or (isinstance(n, ast.FunctionDef) and n.name == "scaled_dot_product_attention")]
+    ns = dict(nn=nn, torch=torch, F=F, np=np, math=math, **ns_ut)
+    ns["SparseAttention"] = None
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "attention.py", "exec"), ns)
+    vq_src = open(os.path.join(base, "vqvae.py")).read()
+    tree = ast.parse(vq_src)
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in
+            ("AxialBlock", "AttentionResidualBlock", "Decoder", "SamePadConv3d", "SamePadConvTranspose3d")]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "vqvae.py", "exec"), ns)
+    return ns

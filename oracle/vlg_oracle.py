@@ -709,3 +709,97 @@ class VAEOracle:
                 h = time_upsample2x(h)
         h = swish(group_norm(h, sd["decoder.norm_out.weight"], sd["decoder.norm_out.bias"]))
         return self._cc("decoder.conv_out", h, 1)
+
+
+# ----------------------------------------------------------------------------
+# tokenizer_video VQ-VAE decode  (tokenizer/tokenizer_video/vqvae.py:48-51,89-125,245-319; attention.py:121-247,496-510)
+# ----------------------------------------------------------------------------
+def batchnorm_eval(x, p, sd, eps=1e-5):
+    sh = (1, -1) + (1,) * (x.ndim - 2)
+    return ((x - sd[p + ".running_mean"].reshape(sh)) / np.sqrt(sd[p + ".running_var"].reshape(sh) + F32(eps)) * sd[p + ".weight"].reshape(sh)
+            + sd[p + ".bias"].reshape(sh)).astype(F32)
+
+
+def same_pad_conv3d(x, w, b):
+    """SamePadConv3d, stride 1 (vqvae.py:276-296): zero pad (p//2 + p%2, p//2) per dim, p = k - 1."""
+    k = w.shape[2:]
+    pads = [(0, 0), (0, 0)] + [((kk - 1) // 2 + (kk - 1) % 2, (kk - 1) // 2) for kk in k]
+    xp = np.pad(x.astype(F32), pads)
+    B, Cin = x.shape[:2]
+    T, H, W = x.shape[2:]
+    out = np.zeros((B, w.shape[0], T * H * W), F32)
+    for a in range(k[0]):
+        for i in range(k[1]):
+            for j in range(k[2]):
+                patch = np.ascontiguousarray(xp[:, :, a:a + T, i:i + H, j:j + W]).reshape(B, Cin, -1)
+                out += np.einsum("oc,bcn->bon", w[:, :, a, i, j].astype(F32), patch, optimize=True)
+    out = out.reshape(B, -1, T, H, W)
+    return out + b.reshape(1, -1, 1, 1, 1) if b is not None else out
+
+
+def same_pad_conv_transpose3d(x, w, b, k=4, s=2):
+    """SamePadConvTranspose3d (vqvae.py:299-319): F.pad by (1,1) per dim (k - s = 2), ConvTranspose3d(k, stride s,
+    padding k - 1).  w [Cin, Cout, k, k, k].  Output size s * n per dim."""
+    xp = np.pad(x.astype(F32), [(0, 0), (0, 0), (1, 1), (1, 1), (1, 1)])
+    B, Cin, Tp, Hp, Wp = xp.shape
+    Cout = w.shape[1]
+    full = np.zeros((B, Cout, (Tp - 1) * s + k, (Hp - 1) * s + k, (Wp - 1) * s + k), F32)
+    for a in range(k):
+        for i in range(k):
+            for j in range(k):
+                contrib = np.einsum("bcthw,co->bothw", xp, w[:, :, a, i, j].astype(F32), optimize=True)
+                full[:, :, a:a + (Tp - 1) * s + 1:s, i:i + (Hp - 1) * s + 1:s, j:j + (Wp - 1) * s + 1:s] += contrib
+    pd = k - 1
+    out = full[:, :, pd:full.shape[2] - pd, pd:full.shape[3] - pd, pd:full.shape[4] - pd]
+    return out + b.reshape(1, -1, 1, 1, 1)
+
+
+class VideoVQVAEOracle:
+    def __init__(self, sd, n_res_layers=4, n_head=2):
+        self.sd = {k: np.asarray(v, F32) for k, v in sd.items()}
+        self.n_res, self.n_head = n_res_layers, n_head
+
+    def _mha(self, p, x, axis):
+        """MultiHeadAttention + AxialAttention (attention.py:121-199,228-247): x [B,t,h,w,C], attention along `axis` (1..3)."""
+        sd, nh = self.sd, self.n_head
+        q = x @ sd[p + ".w_qs.weight"].T
+        k = x @ sd[p + ".w_ks.weight"].T
+        v = x @ sd[p + ".w_vs.weight"].T
+        B = x.shape[0]
+        dk = q.shape[-1] // nh
+
+        def heads(z):
+            z = z.reshape(z.shape[:-1] + (nh, dk))
+            return np.moveaxis(np.moveaxis(z, -2, 1), axis + 1, -2)          # [B, nh, ..., L, dk]
+        qh, kh, vh = heads(q), heads(k), heads(v)
+        att = softmax_lastdim(np.einsum("...id,...jd->...ij", qh, kh) / F32(np.sqrt(dk)))
+        o = np.einsum("...ij,...jd->...id", att, vh)
+        o = np.moveaxis(np.moveaxis(o, -2, axis + 1), 1, -2)
+        o = o.reshape(o.shape[:-2] + (nh * dk,))
+        return (o @ sd[p + ".fc.weight"].T + sd[p + ".fc.bias"]).astype(F32)
+
+    def _res(self, p, x):
+        sd = self.sd                                                               # AttentionResidualBlock, vqvae.py:107-125
+        h = np.maximum(batchnorm_eval(x, p + ".block.0", sd), 0)
+        h = same_pad_conv3d(h, sd[p + ".block.2.conv.weight"], None)
+        h = np.maximum(batchnorm_eval(h, p + ".block.3", sd), 0)
+        h = same_pad_conv3d(h, sd[p + ".block.5.conv.weight"], None)
+        h = np.maximum(batchnorm_eval(h, p + ".block.6", sd), 0)
+        hl = np.moveaxis(h, 1, -1)                                                 # AxialBlock, vqvae.py:100-104
+        a = self._mha(p + ".block.8.attn_w", hl, 3) + self._mha(p + ".block.8.attn_h", hl, 2) + self._mha(p + ".block.8.attn_t", hl, 1)
+        return x + np.moveaxis(a, -1, 1)
+
+    def decode(self, enc):
+        sd = self.sd
+        h = np.moveaxis(sd["codebook.embeddings"][np.asarray(enc)], -1, 1)         # vqvae.py:48-51
+        h = same_pad_conv3d(h, sd["post_vq_conv.conv.weight"], sd["post_vq_conv.conv.bias"])
+        for i in range(self.n_res):
+            h = self._res(f"decoder.res_stack.{i}", h)
+        h = np.maximum(batchnorm_eval(h, f"decoder.res_stack.{self.n_res}", sd), 0)
+        i = 0
+        while f"decoder.convts.{i}.convt.weight" in sd:                             # vqvae.py:266-272
+            h = same_pad_conv_transpose3d(h, sd[f"decoder.convts.{i}.convt.weight"], sd[f"decoder.convts.{i}.convt.bias"])
+            if f"decoder.convts.{i + 1}.convt.weight" in sd:
+                h = np.maximum(h, 0)
+            i += 1
+        return h

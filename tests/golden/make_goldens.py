@@ -286,6 +286,29 @@ def gold_t2vdiff(out):
     out["sched100_coef2"] = gd100.posterior_mean_coef2
 
 
+def gold_videovq(out):
+    """tokenizer_video VQVAE.decode (vqvae.py:48-51): embedding -> post_vq_conv -> Decoder, from the reference's own classes."""
+    ns = ref_harness.load_videovq_classes()
+    cfg = cases.TINY_VIDEOVQ
+    sd = detweights.videovq_weights(cfg)
+    nh = cfg["n_hiddens"]
+    dec = ns["Decoder"](nh, cfg["n_res_layers"], (4, 4, 4)).eval()
+    dsd = {k[len("decoder."):]: t(v) for k, v in sd.items() if k.startswith("decoder.")}
+    full = dec.state_dict()
+    for k, v in dsd.items():
+        assert k in full and tuple(full[k].shape) == tuple(v.shape), (k, full.get(k, torch.zeros(0)).shape, v.shape)
+        full[k] = v
+    dec.load_state_dict(full)
+    pq = ns["SamePadConv3d"](cfg["embedding_dim"], nh, 1)
+    pq.load_state_dict({"conv.weight": t(sd["post_vq_conv.conv.weight"]), "conv.bias": t(sd["post_vq_conv.conv.bias"])})
+    enc = cases.rng(61).integers(0, cfg["n_codes"], size=(2, 2, 3, 4)).astype(np.int64)
+    h = torch.nn.functional.embedding(t(enc), t(sd["codebook.embeddings"]))
+    h = pq(ns["shift_dim"](h, -1, 1))
+    out["videovq_post"] = h.numpy()
+    out["videovq_res0"] = dec.res_stack[0](h).numpy()
+    out["videovq_decode"] = dec(h).numpy()
+
+
 def gold_gptb(out):
     """BASELINE config 1: GPT-B c2i 16x16 greedy fp32, B=1: ids + top1-top2 margins."""
     gptmod, genmod = ref_harness.load_gpt()
@@ -299,7 +322,7 @@ def gold_gptb(out):
     out["gptb_top1"] = srt[:, -1].astype(np.float32)
 
 
-PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff)
+PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff, videovq=gold_videovq)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

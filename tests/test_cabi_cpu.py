@@ -22,7 +22,7 @@ def L():
 def test_header_symbols_exported(L):
     hdr = open(os.path.join(ROOT, "include", "vlg.h")).read()
     names = set(re.findall(r"\b(vlg_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 24
+    assert len(names) >= 28
     lib = L.lib()
     for n in sorted(names):
         assert hasattr(lib, n), n

@@ -133,3 +133,30 @@ def test_vae_errors():
     m2 = V.VAE_models["VAE-16"](hidden_size=32, embed_dim=8).to("cuda")
     with pytest.raises(_lib.VlgError, match="never loaded"):
         m2.decode(torch.zeros(1, 8, 1, 4, 4))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_videovq_decode(golden, dt):
+    """tokenizer_video VQVAE.decode vs the reference's own Decoder classes (tests/golden/videovq.npz)."""
+    import video_llamagen_amd as V
+    g = golden("videovq")
+    cfg = cases.TINY_VIDEOVQ
+    m = V.VQVAE(embedding_dim=cfg["embedding_dim"], n_codes=cfg["n_codes"], n_hiddens=cfg["n_hiddens"], n_res_layers=cfg["n_res_layers"])
+    m.to("cuda", torch.float32 if dt == "fp32" else torch.bfloat16)
+    sd = detweights.videovq_weights(cfg)
+    _, skipped = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert skipped == []
+    enc = cases.rng(61).integers(0, cfg["n_codes"], size=(2, 2, 3, 4)).astype(np.int64)
+    y = to_np(m.decode(torch.from_numpy(enc)))
+    ref = g["videovq_decode"]
+    assert y.shape == ref.shape == (2, 3, 8, 12, 16)
+    err = np.abs(y - ref)
+    scale = np.abs(ref).max()
+    if dt == "fp32":
+        assert err.max() < 2e-3 * scale
+    else:
+        assert err.max() < 5e-2 * scale and np.sqrt((err ** 2).mean()) < 1.5e-2 * scale
+    # Codebook nearest neighbour round trip on this model's codebook
+    E = sd["codebook.embeddings"]
+    z = np.moveaxis(E[enc], -1, 1).copy()
+    assert (m.encode_indices(torch.from_numpy(z)).cpu().numpy() == enc).all()

@@ -176,3 +176,19 @@ def test_diffloss_head(golden):
     ref = g["t2vdiff_latents"]
     assert lat.shape == ref.shape == (1, N, C)
     assert np.abs(lat - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_videovq_decode(golden):
+    """tokenizer_video VQVAE.decode topology (BatchNorm eval, same-pad convs, axial attention, transposed 4^3 convs)."""
+    g = golden("videovq")
+    cfg = cases.TINY_VIDEOVQ
+    sd = detweights.videovq_weights(cfg)
+    vq = O.VideoVQVAEOracle(sd, n_res_layers=cfg["n_res_layers"])
+    enc = cases.rng(61).integers(0, cfg["n_codes"], size=(2, 2, 3, 4)).astype(np.int64)
+    h = np.moveaxis(sd["codebook.embeddings"][enc], -1, 1)
+    h = O.same_pad_conv3d(h, sd["post_vq_conv.conv.weight"], sd["post_vq_conv.conv.bias"])
+    np.testing.assert_allclose(h, g["videovq_post"], atol=1e-5)
+    np.testing.assert_allclose(vq._res("decoder.res_stack.0", h), g["videovq_res0"], atol=2e-4)
+    y = vq.decode(enc)
+    assert y.shape == g["videovq_decode"].shape == (2, 3, 8, 12, 16)
+    np.testing.assert_allclose(y, g["videovq_decode"], atol=2e-3 * np.abs(g["videovq_decode"]).max())

@@ -44,6 +44,10 @@ class VaeConfig(C.Structure):
                 ("spatial_upsample", C.c_int32 * 8), ("temporal_upsample", C.c_int32 * 8), ("dtype", C.c_int32)]
 
 
+class VqvaeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_hiddens", "embedding_dim", "n_codes", "n_res_layers", "n_head", "n_upsample", "dtype")]
+
+
 # every symbol include/vlg.h declares
 SYMBOLS = [
     "vlg_last_error", "vlg_version",
@@ -53,6 +57,7 @@ SYMBOLS = [
     "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",
     "vlg_codebook_argmin",
     "vlg_vae_create", "vlg_vae_destroy", "vlg_vae_load_tensor", "vlg_vae_decode", "vlg_vae_out_shape",
+    "vlg_vqvae_create", "vlg_vqvae_destroy", "vlg_vqvae_load_tensor", "vlg_vqvae_decode",
 ]
 
 _lib = None

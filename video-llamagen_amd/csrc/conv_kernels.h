@@ -10,6 +10,7 @@ struct ConvDesc {
   int To, Ho, Wo, Cout;     // output
   int kt, kh, kw;           // kernel; zero pad kh/2, kw/2 in H/W; causal replicate pad (kt-1) frames in front (conv.py:124-130)
   int up;                   // 1: nearest 2x on H and W applied to the input first (vq_model.py:375; updownsample.py:146-153)
+  int tmode = 0;            // time padding: 0 = causal replicate (CausalConv3d), 1 = symmetric zero pad (SamePadConv3d, vqvae.py:276-296)
 };
 
 // out = conv(in) + bias (+ residual).  w: [Cout][taps][Cin] (re-laid out at load time), bias fp32 [Cout].
@@ -36,6 +37,25 @@ int q12_permute(const T* x, T* y, int B, int T_, int HW, int C, bool inverse, hi
 // TimeUpsample2x (updownsample.py:189-194): [B,T,HW,C] -> [B,2T-1,HW,C]
 template <typename T>
 int time_upsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st);
+
+// ---- tokenizer_video VQ-VAE decoder pieces (tokenizer/tokenizer_video/vqvae.py, attention.py) ----------------------------
+// y = relu(batchnorm_eval(x)) on channels-last data; rm/rv/gamma/beta fp32 [C], eps 1e-5
+template <typename T>
+int bn_relu(const T* x, T* y, const float* gamma, const float* beta, const float* rm, const float* rv, long long n_pos, int C, bool relu,
+            hipStream_t st);
+// SamePadConvTranspose3d(k=4, stride 2) (vqvae.py:299-319): in [B,T,H,W,Cin] -> out [B,2T,2H,2W,Cout]; w [Cout][64][Cin]
+template <typename T>
+int conv_transpose_k4s2(const T* in, const T* w, const float* bias, T* out_cl, float* out_planar, int B, int Ti, int Hi, int Wi, int Cin,
+                        int Cout, bool relu, hipStream_t st);
+// axial multi-head attention along one of the (t,h,w) axes (attention.py:228-247): q,k,v,out [B,T,H,W,nh*dk]
+template <typename T>
+int axial_attention(const T* q, const T* k, const T* v, T* out, int B, int T_, int H, int W, int nh, int dk, int axis, hipStream_t st);
+// out = r + a + b + c (elementwise)
+template <typename T>
+int add4(const T* r, const T* a, const T* b, const T* c, T* out, long long n, hipStream_t st);
+// ConvTranspose3d weight [Cin, Cout, taps] -> [Cout][taps][Cin]
+template <typename T>
+int relayout_convt_weight(const float* src, T* dst, int Cin, int Cout, int taps, hipStream_t st);
 
 // layout / dtype glue
 template <typename T>

@@ -41,8 +41,14 @@ __device__ __forceinline__ PosDec decode_pos(long long p, const ConvDesc& d, lon
 
 // element offset of the input row feeding output position `pd` through tap (a,i,j), or -1 (zero padding)
 __device__ __forceinline__ long long tap_src(const PosDec& pd, const ConvDesc& d, int a, int i, int j) {
-  int ti = pd.t + a - (d.kt - 1);
-  ti = ti < 0 ? 0 : ti;                                   // causal: frame 0 replicated in front (conv.py:126-129)
+  int ti;
+  if (d.tmode == 0) {
+    ti = pd.t + a - (d.kt - 1);
+    ti = ti < 0 ? 0 : ti;                                 // causal: frame 0 replicated in front (conv.py:126-129)
+  } else {
+    ti = pd.t + a - ((d.kt - 1) / 2 + (d.kt - 1) % 2);    // SamePadConv3d: zero pad (p//2 + p%2, p//2)
+    if (ti < 0 || ti >= d.Ti) return -1;
+  }
   const int uy = pd.y + i - d.kh / 2, ux = pd.x + j - d.kw / 2;
   if (!pd.ok || uy < 0 || ux < 0 || uy >= d.Ho || ux >= d.Wo) return -1;   // zero pad of nn.Conv (stride 1, "same")
   const int iy = uy >> d.up, ix = ux >> d.up;             // nearest 2x upsample folded in
@@ -395,6 +401,172 @@ int spatial_attention(const T* q, const T* k, const T* v, T* out, int NF, int HW
 }
 template int spatial_attention<float>(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 template int spatial_attention<bf16>(const bf16*, const bf16*, const bf16*, bf16*, int, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// tokenizer_video VQ-VAE decoder pieces
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv,
+                                                      long long total, int C, int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  float v = (DT<T>::ld(x + i) - rm[c]) / sqrtf(rv[c] + 1e-5f) * gamma[c] + beta[c];
+  if (relu) v = fmaxf(v, 0.f);
+  DT<T>::st(y + i, v);
+}
+template <typename T>
+int bn_relu(const T* x, T* y, const float* gamma, const float* beta, const float* rm, const float* rv, long long n_pos, int C, bool relu,
+            hipStream_t st) {
+  const long long total = n_pos * C;
+  bn_relu_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, gamma, beta, rm, rv, total, C, relu ? 1 : 0);
+  return VLG_OK;
+}
+template int bn_relu<float>(const float*, float*, const float*, const float*, const float*, const float*, long long, int, bool, hipStream_t);
+template int bn_relu<bf16>(const bf16*, bf16*, const float*, const float*, const float*, const float*, long long, int, bool, hipStream_t);
+
+// out[o] = bias + sum over taps k, ci with padded-input index i = (o + 3 - k) / 2 (when even), original index i - 1
+template <typename T>
+__global__ __launch_bounds__(256) void convt_k4s2_kernel(const T* __restrict__ in, const T* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ out_cl, float* __restrict__ out_planar, int B, int Ti, int Hi, int Wi,
+                                                         int Cin, int Cout, int relu) {
+  const int To = 2 * Ti, Ho = 2 * Hi, Wo = 2 * Wi;
+  const long long ptot = (long long)B * To * Ho * Wo;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= ptot * Cout) return;
+  const int co = (int)(gid % Cout);
+  long long p = gid / Cout;
+  const long long pp = p;
+  const int ox = (int)(p % Wo);
+  p /= Wo;
+  const int oy = (int)(p % Ho);
+  p /= Ho;
+  const int ot = (int)(p % To);
+  const int b = (int)(p / To);
+  float acc = bias ? bias[co] : 0.f;
+  for (int a = 0; a < 4; ++a) {
+    const int nt = ot + 3 - a;
+    if (nt & 1) continue;
+    const int it = nt / 2 - 1;
+    if (it < 0 || it >= Ti) continue;
+    for (int i = 0; i < 4; ++i) {
+      const int ny = oy + 3 - i;
+      if (ny & 1) continue;
+      const int iy = ny / 2 - 1;
+      if (iy < 0 || iy >= Hi) continue;
+      for (int j = 0; j < 4; ++j) {
+        const int nx = ox + 3 - j;
+        if (nx & 1) continue;
+        const int ix = nx / 2 - 1;
+        if (ix < 0 || ix >= Wi) continue;
+        const T* xi = in + ((((long long)b * Ti + it) * Hi + iy) * Wi + ix) * Cin;
+        const T* wi = w + ((size_t)co * 64 + (a * 16 + i * 4 + j)) * Cin;
+        for (int c = 0; c < Cin; ++c) acc = fmaf(DT<T>::ld(xi + c), DT<T>::ld(wi + c), acc);
+      }
+    }
+  }
+  if (relu) acc = fmaxf(acc, 0.f);
+  const long long pper = (long long)To * Ho * Wo;
+  if (out_cl)
+    DT<T>::st(out_cl + pp * Cout + co, acc);
+  else
+    out_planar[((pp / pper) * Cout + co) * pper + (pp % pper)] = acc;
+}
+template <typename T>
+int conv_transpose_k4s2(const T* in, const T* w, const float* bias, T* out_cl, float* out_planar, int B, int Ti, int Hi, int Wi, int Cin,
+                        int Cout, bool relu, hipStream_t st) {
+  const long long total = (long long)B * 8 * Ti * Hi * Wi * Cout;
+  convt_k4s2_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(in, w, bias, out_cl, out_planar, B, Ti, Hi, Wi, Cin, Cout, relu ? 1 : 0);
+  return VLG_OK;
+}
+template int conv_transpose_k4s2<float>(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, bool, hipStream_t);
+template int conv_transpose_k4s2<bf16>(const bf16*, const bf16*, const float*, bf16*, float*, int, int, int, int, int, int, bool, hipStream_t);
+
+// one wave per (position, head): online softmax over the L positions along `axis`
+template <typename T>
+__global__ __launch_bounds__(256) void axial_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                         T* __restrict__ out, long long nq, int Tn, int H, int W, int nh, int dk, int axis) {
+  const int lane = threadIdx.x & 63;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= nq) return;
+  const int head = (int)(wid % nh);
+  const long long pos = wid / nh;   // flat (b,t,h,w)
+  const int C = nh * dk;
+  const int x = (int)(pos % W), y = (int)((pos / W) % H), tt = (int)((pos / ((long long)W * H)) % Tn);
+  const long long b = pos / ((long long)W * H * Tn);
+  const int L = axis == 1 ? Tn : (axis == 2 ? H : W);
+  const long long stride = axis == 1 ? (long long)H * W : (axis == 2 ? W : 1);
+  const long long base = (b * Tn * H * W) + (axis == 1 ? (long long)y * W + x : (axis == 2 ? (long long)tt * H * W + x : ((long long)tt * H + y) * W));
+  const int e0 = lane * 2;          // dk <= 128: two elements per lane
+  float q0 = 0.f, q1 = 0.f;
+  if (e0 < dk) q0 = DT<T>::ld(q + pos * C + head * dk + e0);
+  if (e0 + 1 < dk) q1 = DT<T>::ld(q + pos * C + head * dk + e0 + 1);
+  const float scale = 1.0f / sqrtf((float)dk);
+  float mx = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const long long pj = base + j * stride;
+    float d = 0.f;
+    if (e0 < dk) d += q0 * DT<T>::ld(k + pj * C + head * dk + e0);
+    if (e0 + 1 < dk) d += q1 * DT<T>::ld(k + pj * C + head * dk + e0 + 1);
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    d *= scale;
+    const float mn = fmaxf(mx, d);
+    const float al = __expf(mx - mn), pj2 = __expf(d - mn);
+    l = l * al + pj2;
+    a0 = a0 * al + (e0 < dk ? pj2 * DT<T>::ld(v + pj * C + head * dk + e0) : 0.f);
+    a1 = a1 * al + (e0 + 1 < dk ? pj2 * DT<T>::ld(v + pj * C + head * dk + e0 + 1) : 0.f);
+    mx = mn;
+  }
+  if (e0 < dk) DT<T>::st(out + pos * C + head * dk + e0, a0 / l);
+  if (e0 + 1 < dk) DT<T>::st(out + pos * C + head * dk + e0 + 1, a1 / l);
+}
+template <typename T>
+int axial_attention(const T* q, const T* k, const T* v, T* out, int B, int T_, int H, int W, int nh, int dk, int axis, hipStream_t st) {
+  if (dk > 128 || axis < 1 || axis > 3) {
+    set_error("axial_attention: unsupported head dim %d / axis %d", dk, axis);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  const long long nq = (long long)B * T_ * H * W * nh;
+  axial_attn_kernel<T><<<dim3((unsigned)cdiv64(nq, 4)), 256, 0, st>>>(q, k, v, out, nq, T_, H, W, nh, dk, axis);
+  return VLG_OK;
+}
+template int axial_attention<float>(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+template int axial_attention<bf16>(const bf16*, const bf16*, const bf16*, bf16*, int, int, int, int, int, int, int, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void add4_kernel(const T* __restrict__ r, const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                   T* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  DT<T>::st(out + i, DT<T>::ld(r + i) + ((DT<T>::ld(a + i) + DT<T>::ld(b + i)) + DT<T>::ld(c + i)));
+}
+template <typename T>
+int add4(const T* r, const T* a, const T* b, const T* c, T* out, long long n, hipStream_t st) {
+  add4_kernel<T><<<dim3((unsigned)cdiv64(n, 256)), 256, 0, st>>>(r, a, b, c, out, n);
+  return VLG_OK;
+}
+template int add4<float>(const float*, const float*, const float*, const float*, float*, long long, hipStream_t);
+template int add4<bf16>(const bf16*, const bf16*, const bf16*, const bf16*, bf16*, long long, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void relayout_wt_kernel(const float* __restrict__ src, T* __restrict__ dst, int Cin, int Cout, int taps, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i % Cin);
+  const long long r = i / Cin;
+  const int tap = (int)(r % taps);
+  const long long co = r / taps;
+  DT<T>::st(dst + i, src[((long long)ci * Cout + co) * taps + tap]);
+}
+template <typename T>
+int relayout_convt_weight(const float* src, T* dst, int Cin, int Cout, int taps, hipStream_t st) {
+  const long long total = (long long)Cin * Cout * taps;
+  relayout_wt_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(src, dst, Cin, Cout, taps, total);
+  return VLG_OK;
+}
+template int relayout_convt_weight<float>(const float*, float*, int, int, int, hipStream_t);
+template int relayout_convt_weight<bf16>(const float*, bf16*, int, int, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
 // layout glue

@@ -34,6 +34,7 @@ struct Store {
   std::vector<bool> busy;
   DevBuf stats, staging;
   hipStream_t st = nullptr;
+  bool linear_as_conv = false;   // 2-D nn.Linear weights stored like 1x1 conv weights (tokenizer_video attention)
 
   bool skip(const std::string& n) const {
     return n.rfind("encoder.", 0) == 0 || n.rfind("quant_conv", 0) == 0 || n.rfind("loss", 0) == 0 ||
@@ -51,9 +52,23 @@ struct Store {
     Param& p = params[n];
     VLG_TRY(staging.reserve((size_t)total * sizeof(float)));
     VLG_TRY(upload_convert(staging.p, VLG_F32, data, src_dtype, on_dev, total, nullptr));
-    if (ndim >= 4) {  // conv weight [Cout, Cin, (kt,) kh, kw]
+    const bool is_convt = n.find(".convt.weight") != std::string::npos;
+    const bool lin = linear_as_conv && ndim == 2 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0 &&
+                     n.find("embeddings") == std::string::npos;
+    if (is_convt && ndim == 5) {  // ConvTranspose3d weight [Cin, Cout, k, k, k] -> [Cout][taps][Cin]
+      const int Cin = (int)shape[0], Cout = (int)shape[1];
+      p.shape = {Cout, Cin, shape[2], shape[3], shape[4]};
+      p.conv = true;
+      VLG_TRY(p.buf.reserve((size_t)total * esz));
+      const int taps = (int)(shape[2] * shape[3] * shape[4]);
+      if (dtype == VLG_BF16)
+        VLG_TRY(relayout_convt_weight<bf16>(staging.as<float>(), p.buf.as<bf16>(), Cin, Cout, taps, nullptr));
+      else
+        VLG_TRY(relayout_convt_weight<float>(staging.as<float>(), p.buf.as<float>(), Cin, Cout, taps, nullptr));
+      VLG_HIP(hipStreamSynchronize(nullptr));
+    } else if (ndim >= 4 || lin) {  // conv weight [Cout, Cin, (kt,) kh, kw]; Linear [out, in] == 1x1 conv
       const int Cout = (int)shape[0], Cin = (int)shape[1];
-      const int kt = ndim == 5 ? (int)shape[2] : 1, kh = (int)shape[ndim - 2], kw = (int)shape[ndim - 1];
+      const int kt = ndim == 5 ? (int)shape[2] : 1, kh = lin ? 1 : (int)shape[ndim - 2], kw = lin ? 1 : (int)shape[ndim - 1];
       p.shape = {Cout, Cin, kt, kh, kw};
       p.conv = true;
       VLG_TRY(p.buf.reserve((size_t)total * esz));
@@ -115,6 +130,8 @@ struct Net {
   hipStream_t st;
   std::string csuf;  // ".conv" for CausalConv3d wrappers, "" for nn.Conv2d
 
+  int tmode = 0;     // 1: SamePadConv3d (symmetric zero time pad) instead of CausalConv3d
+
   int conv(const Act& x, const std::string& name, int up, const Act* residual, Act& y, float* planar_out = nullptr) {
     const Param* w = s.find(name + csuf + ".weight");
     const Param* b = s.find(name + csuf + ".bias");
@@ -125,6 +142,7 @@ struct Net {
     d.To = x.T; d.Ho = x.H << up; d.Wo = x.W << up; d.Cout = (int)w->shape[0];
     d.kt = (int)w->shape[2]; d.kh = (int)w->shape[3]; d.kw = (int)w->shape[4];
     d.up = up;
+    d.tmode = tmode;
     y.B = d.B; y.T = d.To; y.H = d.Ho; y.W = d.Wo; y.C = d.Cout;
     if (residual) VLG_CHECK(residual->numel() == y.numel(), VLG_ERR_BAD_SHAPE, "%s: residual shape mismatch", name.c_str());
     if (!planar_out) VLG_TRY(s.get((size_t)y.numel() * sizeof(T), y));
@@ -419,4 +437,141 @@ extern "C" int vlg_vae_decode(vlg_vae_t* h, const float* d_z, int32_t B, int32_t
   VLG_CHECK(h && d_z && d_out && B > 0 && t > 0 && hh > 0 && ww > 0, VLG_ERR_BAD_ARG, "vlg_vae_decode: bad argument");
   if (h->s.dtype == VLG_BF16) return vae_decode_impl<bf16>(h, d_z, B, t, hh, ww, d_out, (hipStream_t)stream);
   return vae_decode_impl<float>(h, d_z, B, t, hh, ww, d_out, (hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// tokenizer_video VQ-VAE decode
+// ---------------------------------------------------------------------------------------------------------------
+struct vlg_vqvae {
+  vlg_vqvae_config cfg;
+  Store s;
+};
+
+extern "C" int vlg_vqvae_create(const vlg_vqvae_config* cfg, vlg_vqvae_t** out) {
+  VLG_CHECK(cfg && out, VLG_ERR_BAD_ARG, "vlg_vqvae_create: null argument");
+  VLG_CHECK(cfg->dtype == VLG_F32 || cfg->dtype == VLG_BF16, VLG_ERR_UNSUPPORTED, "vlg_vqvae_create: dtype %d", cfg->dtype);
+  VLG_CHECK(cfg->n_hiddens > 0 && cfg->n_head > 0 && cfg->n_hiddens % cfg->n_head == 0 && cfg->n_hiddens / cfg->n_head <= 128 &&
+                cfg->n_codes > 0 && cfg->embedding_dim > 0 && cfg->n_res_layers >= 0 && cfg->n_upsample >= 1,
+            VLG_ERR_BAD_ARG, "vlg_vqvae_create: bad config");
+  std::unique_ptr<vlg_vqvae> h(new vlg_vqvae());
+  h->cfg = *cfg;
+  h->s.dtype = cfg->dtype;
+  h->s.esz = dtype_size(cfg->dtype);
+  h->s.linear_as_conv = true;
+  *out = h.release();
+  return VLG_OK;
+}
+extern "C" int vlg_vqvae_destroy(vlg_vqvae_t* h) {
+  if (h) {
+    (void)hipDeviceSynchronize();
+    delete h;
+  }
+  return VLG_OK;
+}
+extern "C" int vlg_vqvae_load_tensor(vlg_vqvae_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                                     int32_t src_dtype, int32_t on_dev, int32_t* consumed) {
+  VLG_CHECK(h && name && data && shape, VLG_ERR_BAD_ARG, "vlg_vqvae_load_tensor: null argument");
+  const std::string n(name);
+  if (n.rfind("pre_vq_conv", 0) == 0 || n == "codebook.N" || n == "codebook.z_avg" || n.find("num_batches_tracked") != std::string::npos) {
+    if (consumed) *consumed = 0;   // encode / EMA-training side
+    return VLG_OK;
+  }
+  return h->s.load(name, data, shape, ndim, src_dtype, on_dev, consumed);
+}
+
+template <typename T>
+static int vqvae_decode_impl(vlg_vqvae* h, const int32_t* codes, int B, int t, int hh, int ww, float* out, hipStream_t st) {
+  Store& s = h->s;
+  s.st = st;
+  s.release_all();
+  Net<T> net{s, st, ".conv"};
+  net.tmode = 1;
+  const int NH = h->cfg.n_hiddens, nhd = h->cfg.n_head, dk = NH / nhd;
+  const Param* E = s.find("codebook.embeddings");
+  VLG_CHECK(E && E->shape.size() == 2 && E->shape[0] == h->cfg.n_codes && E->shape[1] == h->cfg.embedding_dim, VLG_ERR_STATE,
+            "codebook.embeddings missing or mis-shaped");
+  Act z, x;
+  z.B = B; z.T = t; z.H = hh; z.W = ww; z.C = h->cfg.embedding_dim;
+  VLG_TRY(s.get((size_t)z.numel() * sizeof(T), z));
+  VLG_TRY(codebook_lookup<T>(E->buf.as<float>(), codes, (T*)z.p, (long long)B * t * hh * ww, h->cfg.n_codes, z.C, false, st));   // vqvae.py:49
+  VLG_TRY(net.conv(z, "post_vq_conv", 0, nullptr, x));                                                                          // :50
+  s.put(z);
+  auto bn = [&](const Act& in, const std::string& p, Act& o) -> int {
+    const Param *g = s.find(p + ".weight"), *b = s.find(p + ".bias"), *rm = s.find(p + ".running_mean"), *rv = s.find(p + ".running_var");
+    VLG_CHECK(g && b && rm && rv, VLG_ERR_STATE, "BatchNorm %s was never loaded", p.c_str());
+    VLG_CHECK(g->shape[0] == in.C, VLG_ERR_BAD_SHAPE, "%s: channel mismatch", p.c_str());
+    o = in;
+    o.slot = -1;
+    VLG_TRY(s.get((size_t)in.numel() * sizeof(T), o));
+    return bn_relu<T>((const T*)in.p, (T*)o.p, g->buf.as<float>(), b->buf.as<float>(), rm->buf.as<float>(), rv->buf.as<float>(),
+                      (long long)in.B * in.P(), in.C, true, st);
+  };
+  for (int i = 0; i < h->cfg.n_res_layers; ++i) {   // AttentionResidualBlock, vqvae.py:107-125
+    const std::string p = "decoder.res_stack." + std::to_string(i) + ".block.";
+    Act a, b2, c;
+    VLG_TRY(bn(x, p + "0", a));
+    VLG_TRY(net.conv(a, p + "2", 0, nullptr, b2));
+    s.put(a);
+    VLG_TRY(bn(b2, p + "3", a));
+    s.put(b2);
+    VLG_TRY(net.conv(a, p + "5", 0, nullptr, b2));
+    s.put(a);
+    VLG_TRY(bn(b2, p + "6", c));
+    s.put(b2);
+    // AxialBlock (vqvae.py:89-104): attn_w + attn_h + attn_t, each MultiHeadAttention(q = k = v = c)
+    Act outs[3];
+    const char* names[3] = {"attn_w", "attn_h", "attn_t"};
+    const int axes[3] = {3, 2, 1};
+    Net<T> lin{s, st, ""};
+    for (int k = 0; k < 3; ++k) {
+      const std::string q = p + "8." + names[k] + ".";
+      Act qq, kk, vv, oo;
+      VLG_TRY(lin.conv(c, q + "w_qs", 0, nullptr, qq));
+      VLG_TRY(lin.conv(c, q + "w_ks", 0, nullptr, kk));
+      VLG_TRY(lin.conv(c, q + "w_vs", 0, nullptr, vv));
+      oo = qq;
+      oo.slot = -1;
+      VLG_TRY(s.get((size_t)qq.numel() * sizeof(T), oo));
+      VLG_TRY(axial_attention<T>((const T*)qq.p, (const T*)kk.p, (const T*)vv.p, (T*)oo.p, c.B, c.T, c.H, c.W, nhd, dk, axes[k], st));
+      s.put(qq);
+      s.put(kk);
+      s.put(vv);
+      VLG_TRY(lin.conv(oo, q + "fc", 0, nullptr, outs[k]));
+      s.put(oo);
+    }
+    s.put(c);
+    Act nx = x;
+    nx.slot = -1;
+    VLG_TRY(s.get((size_t)x.numel() * sizeof(T), nx));
+    VLG_TRY(add4<T>((const T*)x.p, (const T*)outs[0].p, (const T*)outs[1].p, (const T*)outs[2].p, (T*)nx.p, x.numel(), st));
+    for (auto& o : outs) s.put(o);
+    s.put(x);
+    x = nx;
+  }
+  Act y;
+  VLG_TRY(bn(x, "decoder.res_stack." + std::to_string(h->cfg.n_res_layers), y));
+  s.put(x);
+  for (int i = 0; i < h->cfg.n_upsample; ++i) {   // vqvae.py:266-272
+    const std::string p = "decoder.convts." + std::to_string(i) + ".convt";
+    const Param *w = s.find(p + ".weight"), *b = s.find(p + ".bias");
+    VLG_CHECK(w && w->conv && b, VLG_ERR_STATE, "%s was never loaded", p.c_str());
+    VLG_CHECK(w->shape[1] == y.C && w->shape[2] == 4, VLG_ERR_BAD_SHAPE, "%s: shape mismatch", p.c_str());
+    const bool last = i == h->cfg.n_upsample - 1;
+    Act o;
+    o.B = y.B; o.T = 2 * y.T; o.H = 2 * y.H; o.W = 2 * y.W; o.C = (int)w->shape[0];
+    if (!last) VLG_TRY(s.get((size_t)o.numel() * sizeof(T), o));
+    VLG_TRY(conv_transpose_k4s2<T>((const T*)y.p, w->buf.as<T>(), b->buf.as<float>(), last ? nullptr : (T*)o.p, last ? out : nullptr, y.B, y.T,
+                                   y.H, y.W, y.C, o.C, !last, st));
+    s.put(y);
+    y = o;
+  }
+  return VLG_OK;
+}
+
+extern "C" int vlg_vqvae_decode(vlg_vqvae_t* h, const int32_t* d_codes, int32_t B, int32_t t, int32_t hh, int32_t ww, float* d_out,
+                                void* stream) {
+  VLG_CHECK(h && d_codes && d_out && B > 0 && t > 0 && hh > 0 && ww > 0, VLG_ERR_BAD_ARG, "vlg_vqvae_decode: bad argument");
+  if (h->s.dtype == VLG_BF16) return vqvae_decode_impl<bf16>(h, d_codes, B, t, hh, ww, d_out, (hipStream_t)stream);
+  return vqvae_decode_impl<float>(h, d_codes, B, t, hh, ww, d_out, (hipStream_t)stream);
 }
