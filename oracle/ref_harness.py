@@ -130,3 +130,18 @@ def load_videovq_classes():
             ("AxialBlock", "AttentionResidualBlock", "Decoder", "SamePadConv3d", "SamePadConvTranspose3d")]
     exec(compile(ast.Module(body=keep, type_ignores=[]), "vqvae.py", "exec"), ns)
     return ns
+
+
+def load_vae_tiling_methods():
+    """CausalVAEModel's tiled_decode / tiled_decode2d / blend_v / blend_h as plain functions (the class itself needs diffusers)."""
+    import torch
+    path = os.path.join(REF, "CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CausalVAEModel"][0]
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("tiled_decode", "tiled_decode2d", "blend_v", "blend_h")]
+    stub = ast.ClassDef(name="TilingStub", bases=[], keywords=[], body=keep, decorator_list=[])
+    mod = ast.Module(body=[stub], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = dict(torch=torch)
+    exec(compile(mod, path, "exec"), ns)
+    return ns["TilingStub"]

@@ -711,6 +711,54 @@ class VAEOracle:
         return self._cc("decoder.conv_out", h, 1)
 
 
+def vae_tiled_decode(decode_fn, x, tile_latent_min_size, tile_latent_min_size_t, tile_sample_min_size, overlap_factor=0.125):
+    """CausalVAEModel.tiled_decode / tiled_decode2d / blend_v / blend_h (modeling_causalvae.py:424-443,468-570) over a plain
+    `decode_fn(z) -> [B,3,T,H,W]` (numpy)."""
+    def blend(a, b, extent, axis):
+        extent = min(a.shape[axis], b.shape[axis], extent)
+        for y in range(extent):
+            ia = [slice(None)] * 5
+            ib = [slice(None)] * 5
+            ia[axis] = -extent + y
+            ib[axis] = y
+            b[tuple(ib)] = a[tuple(ia)] * F32(1 - y / extent) + b[tuple(ib)] * F32(y / extent)
+        return b
+
+    def decode2d(z):
+        overlap = int(tile_latent_min_size * (1 - overlap_factor))
+        extent = int(tile_sample_min_size * overlap_factor)
+        limit = tile_sample_min_size - extent
+        rows = [[decode_fn(z[:, :, :, i:i + tile_latent_min_size, j:j + tile_latent_min_size]).copy()
+                 for j in range(0, z.shape[4], overlap)] for i in range(0, z.shape[3], overlap)]
+        out_rows = []
+        for i, row in enumerate(rows):
+            res = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = blend(rows[i - 1][j], tile, extent, 3)
+                if j > 0:
+                    tile = blend(row[j - 1], tile, extent, 4)
+                res.append(tile[:, :, :, :limit, :limit])
+            out_rows.append(np.concatenate(res, axis=4))
+        return np.concatenate(out_rows, axis=3)
+
+    t = x.shape[2]
+    idx = list(range(0, t, tile_latent_min_size_t - 1))
+    if len(idx) == 1 and idx[0] == 0:
+        se = [[0, t]]
+    else:
+        se = [[idx[i], idx[i + 1] + 1] for i in range(len(idx) - 1)]
+        if se[-1][-1] > t:
+            se[-1][-1] = t
+        elif se[-1][-1] < t:
+            se.append([idx[-1], t])
+    outs = []
+    for k, (a, b) in enumerate(se):
+        d = decode2d(x[:, :, a:b])
+        outs.append(d[:, :, 1:] if k else d)
+    return np.concatenate(outs, axis=2)
+
+
 # ----------------------------------------------------------------------------
 # tokenizer_video VQ-VAE decode  (tokenizer/tokenizer_video/vqvae.py:48-51,89-125,245-319; attention.py:121-247,496-510)
 # ----------------------------------------------------------------------------

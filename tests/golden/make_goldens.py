@@ -203,6 +203,13 @@ def gold_vae(out):
     x2 = cases.rng(34).standard_normal((1, 4, 5, 2, 2), dtype=np.float32)
     out["vae_timeup"] = mods.TimeUpsample2x(4, 4)(t(x2)).numpy()
     out["vae_conv_in"] = dec.conv_in(pq(t(z))).numpy()
+    # tiled decode (modeling_causalvae.py:468-570) with toy tile sizes so that a [1,C,5,6,6] latent tiles in t, h and w
+    Stub = ref_harness.load_vae_tiling_methods()
+    st = Stub()
+    st.decoder, st.post_quant_conv, st.use_quant_layer = dec, pq, True
+    st.tile_sample_min_size, st.tile_latent_min_size, st.tile_latent_min_size_t, st.tile_overlap_factor = 32, 4, 3, 0.25
+    zt = cases.rng(35).standard_normal((1, cfg["embed_dim"], 5, 6, 6), dtype=np.float32)
+    out["vae_tiled"] = st.tiled_decode(t(zt)).numpy()
 
 
 def gold_t2v(out):

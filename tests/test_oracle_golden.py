@@ -135,6 +135,19 @@ def test_vae_decode(golden):
     np.testing.assert_allclose(vae.decode(z1), g["vae_decode_1f"], atol=2e-3 * np.abs(g["vae_decode_1f"]).max())
 
 
+def test_vae_tiled_decode(golden):
+    """CausalVAEModel.tiled_decode (modeling_causalvae.py:468-570) with toy tile sizes: temporal chunks + blended spatial tiles."""
+    g = golden("vae")
+    cfg = cases.TINY_VAE
+    vae = O.VAEOracle(detweights.vae_weights(cfg), hidden_size=cfg["hidden_size"], hidden_size_mult=cfg["hidden_size_mult"],
+                      num_res_blocks=cfg["num_res_blocks"])
+    zt = cases.rng(35).standard_normal((1, cfg["embed_dim"], 5, 6, 6), dtype=np.float32)
+    y = O.vae_tiled_decode(vae.decode, zt, 4, 3, 32, 0.25)
+    ref = g["vae_tiled"]
+    assert y.shape == ref.shape == (1, 3, 17, 48, 48)
+    np.testing.assert_allclose(y, ref, atol=2e-3 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_t2v_adapter2(golden, dt):
     g = golden("t2v")

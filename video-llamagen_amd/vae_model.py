@@ -2,7 +2,8 @@
 
 `VAE_models['VAE-16']` (tokenizer/tokenizer_image/vae_model.py:8) -> object with `.config.embed_dim`, `.enable_tiling()`,
 `.tile_overlap_factor`, `.to(dtype)`, `.load_state_dict`, `.decode(z[B,C,t,h,w]) -> [B,3,T,H,W]`.  Tiling never triggers below
-the reference's own thresholds; above them this build raises instead of silently changing semantics.
+the reference's own thresholds; above them `tiled_decode` mirrors modeling_causalvae.py:468-570 (host-level
+orchestration over plain decodes + linear blending).
 """
 import ctypes as C
 from types import SimpleNamespace
@@ -145,10 +146,69 @@ class CausalVAEModel:
         self._ensure_handle()
         if z.dim() != 5 or z.shape[1] != self.config.embed_dim:
             raise L.VlgError(-2, "z must be [B, %d, t, h, w], got %s" % (self.config.embed_dim, tuple(z.shape)))
+        if self.use_tiling and (z.shape[-1] > self.tile_latent_min_size or z.shape[-2] > self.tile_latent_min_size
+                                or z.shape[-3] > self.tile_latent_min_size_t):
+            return self.tiled_decode(z)
+        return self._decode_plain(z)
+
+    # ---- tiling (modeling_causalvae.py:424-443,468-570): host-level orchestration over plain decodes; tiles overlap and are
+    # blended linearly, temporal chunks overlap by one latent frame whose first decoded frame is dropped ----------------------
+    @staticmethod
+    def blend_v(a, b, blend_extent):
+        blend_extent = min(a.shape[3], b.shape[3], blend_extent)
+        for y in range(blend_extent):
+            b[:, :, :, y, :] = a[:, :, :, -blend_extent + y, :] * (1 - y / blend_extent) + b[:, :, :, y, :] * (y / blend_extent)
+        return b
+
+    @staticmethod
+    def blend_h(a, b, blend_extent):
+        blend_extent = min(a.shape[4], b.shape[4], blend_extent)
+        for x in range(blend_extent):
+            b[:, :, :, :, x] = a[:, :, :, :, -blend_extent + x] * (1 - x / blend_extent) + b[:, :, :, :, x] * (x / blend_extent)
+        return b
+
+    def tiled_decode(self, x):
+        t = x.shape[2]
+        t_chunk_idx = [i for i in range(0, t, self.tile_latent_min_size_t - 1)]
+        if len(t_chunk_idx) == 1 and t_chunk_idx[0] == 0:
+            t_chunk_start_end = [[0, t]]
+        else:
+            t_chunk_start_end = [[t_chunk_idx[i], t_chunk_idx[i + 1] + 1] for i in range(len(t_chunk_idx) - 1)]
+            if t_chunk_start_end[-1][-1] > t:
+                t_chunk_start_end[-1][-1] = t
+            elif t_chunk_start_end[-1][-1] < t:
+                t_chunk_start_end.append([t_chunk_idx[-1], t])
+        dec_ = []
+        for idx, (start, end) in enumerate(t_chunk_start_end):
+            dec = self.tiled_decode2d(x[:, :, start:end])
+            dec_.append(dec[:, :, 1:] if idx != 0 else dec)
+        return torch.cat(dec_, dim=2)
+
+    def tiled_decode2d(self, z):
+        overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        blend_extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
+        row_limit = self.tile_sample_min_size - blend_extent
+        rows = []
+        for i in range(0, z.shape[3], overlap_size):
+            row = []
+            for j in range(0, z.shape[4], overlap_size):
+                tile = z[:, :, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size]
+                row.append(self._decode_plain(tile))          # post_quant_conv + decoder on the GPU (libvlg)
+            rows.append(row)
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self.blend_v(rows[i - 1][j], tile, blend_extent)
+                if j > 0:
+                    tile = self.blend_h(row[j - 1], tile, blend_extent)
+                result_row.append(tile[:, :, :, :row_limit, :row_limit])
+            result_rows.append(torch.cat(result_row, dim=4))
+        return torch.cat(result_rows, dim=3)
+
+    def _decode_plain(self, z):
         B, _, t, hh, ww = [int(s) for s in z.shape]
-        if self.use_tiling and (ww > self.tile_latent_min_size or hh > self.tile_latent_min_size or t > self.tile_latent_min_size_t):
-            raise L.VlgError(-3, "tiled_decode (latent > %dx%d or > %d frames) is not implemented" %
-                             (self.tile_latent_min_size, self.tile_latent_min_size, self.tile_latent_min_size_t))
         zf = z.to(device=self._device, dtype=torch.float32).contiguous()
         T, H, W = C.c_int32(), C.c_int32(), C.c_int32()
         L.check(L.lib().vlg_vae_out_shape(self._handle, t, hh, ww, C.byref(T), C.byref(H), C.byref(W)))
