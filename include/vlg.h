@@ -147,6 +147,9 @@ int vlg_vq_decode_code(vlg_vq_t* h, const int32_t* d_codes, int32_t B, int32_t g
                        void* stream);
 /* VectorQuantizer.forward indices vq_model.py:215-233: d_z fp32 [B,C,H,W] -> int32 [B*H*W]            */
 int vlg_vq_argmin(vlg_vq_t* h, const float* d_z, int32_t B, int32_t Hh, int32_t Ww, int32_t* d_idx, void* stream);
+/* VQModel.encode vq_model.py:41-45 (Encoder :64-124 -> quant_conv -> VectorQuantizer argmin): d_x fp32 [B,3,H,W] -> int32
+ * [B*(H/16)*(W/16)] indices; d_z (optional) receives the pre-quantisation latents fp32 [B, e_dim, H/16, W/16]            */
+int vlg_vq_encode(vlg_vq_t* h, const float* d_x, int32_t B, int32_t Hh, int32_t Ww, int32_t* d_idx, float* d_z, void* stream);
 /* Codebook.forward argmin, tokenizer_video/vqvae.py:161-170 (== CausalVideoVAE quant.py:42-54):
  * d_z fp32 [n, dim] rows, d_codebook fp32 [n_codes, dim] -> int32 [n] (no normalisation)              */
 int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim,
@@ -191,6 +194,9 @@ int vlg_vae_load_tensor(vlg_vae_t* h, const char* name, const void* data, const 
 int vlg_vae_decode(vlg_vae_t* h, const float* d_z, int32_t B, int32_t t, int32_t hh, int32_t ww, float* d_out,
                    void* stream);
 int vlg_vae_out_shape(vlg_vae_t* h, int32_t t, int32_t hh, int32_t ww, int32_t* T, int32_t* H, int32_t* W);
+/* CausalVAEModel.encode up to the posterior parameters, modeling_causalvae.py:382-392 (Encoder :26-148 -> quant_conv):
+ * d_x fp32 [B,3,T,H,W] -> d_moments fp32 [B, 2*embed_dim, (T-1)/4+1, H/8, W/8] = [mean | logvar]                      */
+int vlg_vae_encode(vlg_vae_t* h, const float* d_x, int32_t B, int32_t T_, int32_t Hh, int32_t Ww, float* d_moments, void* stream);
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,94 @@ def vq_weights(cfg=None, seed=1234):
     return sd
 
 
+def vq_encoder_weights(cfg=None, seed=1234):
+    """VQ-16 encoder + quant_conv (vq_model.py:64-103,38)."""
+    cfg = dict(cfg or {})
+    ch = cfg.get("ch", 128)
+    ch_mult = cfg.get("ch_mult", (1, 1, 2, 2, 4))
+    zc = cfg.get("z_channels", 256)
+    e_dim = cfg.get("codebook_embed_dim", 8)
+    sd = {}
+    _conv(sd, "encoder.conv_in", ch, 3, 3, seed)
+
+    def res(prefix, cin, cout):
+        _gn(sd, prefix + ".norm1", cin, seed)
+        _conv(sd, prefix + ".conv1", cout, cin, 3, seed)
+        _gn(sd, prefix + ".norm2", cout, seed)
+        _conv(sd, prefix + ".conv2", cout, cout, 3, seed, gain=0.5)
+        if cin != cout:
+            _conv(sd, prefix + ".nin_shortcut", cout, cin, 1, seed)
+
+    def attn(prefix, c):
+        _gn(sd, prefix + ".norm", c, seed)
+        for n in ("q", "k", "v"):
+            _conv(sd, prefix + "." + n, c, c, 1, seed)
+        _conv(sd, prefix + ".proj_out", c, c, 1, seed, gain=0.5)
+
+    in_mult = (1,) + tuple(ch_mult)
+    nres = len(ch_mult)
+    block_in = ch
+    for li in range(nres):
+        block_in = ch * in_mult[li]
+        block_out = ch * ch_mult[li]
+        for j in range(2):
+            res(f"encoder.conv_blocks.{li}.res.{j}", block_in, block_out)
+            block_in = block_out
+            if li == nres - 1:
+                attn(f"encoder.conv_blocks.{li}.attn.{j}", block_in)
+        if li != nres - 1:
+            _conv(sd, f"encoder.conv_blocks.{li}.downsample.conv", block_in, block_in, 3, seed)
+    res("encoder.mid.0", block_in, block_in)
+    attn("encoder.mid.1", block_in)
+    res("encoder.mid.2", block_in, block_in)
+    _gn(sd, "encoder.norm_out", block_in, seed)
+    _conv(sd, "encoder.conv_out", zc, block_in, 3, seed)
+    _conv(sd, "quant_conv", e_dim, zc, 1, seed)
+    return sd
+
+
+def vae_encoder_weights(cfg=None, seed=1234):
+    """CausalVAEModel encoder + quant_conv (modeling_causalvae.py:26-148,368)."""
+    cfg = dict(cfg or {})
+    hs = cfg.get("hidden_size", 128)
+    mult = cfg.get("hidden_size_mult", (1, 2, 4, 4))
+    zc = cfg.get("z_channels", 4)
+    ed = cfg.get("embed_dim", 4)
+    nrb = cfg.get("num_res_blocks", 2)
+    sdn = cfg.get("spatial_downsample", (True, True, True, False))
+    sd = {}
+    _conv(sd, "encoder.conv_in.conv", hs, 3, 3, seed, nd=3)
+
+    def res(prefix, cin, cout):
+        _gn(sd, prefix + ".norm1", cin, seed)
+        _conv(sd, prefix + ".conv1.conv", cout, cin, 3, seed, nd=3)
+        _gn(sd, prefix + ".norm2", cout, seed)
+        _conv(sd, prefix + ".conv2.conv", cout, cout, 3, seed, nd=3, gain=0.5)
+        if cin != cout:
+            _conv(sd, prefix + ".nin_shortcut.conv", cout, cin, 1, seed, nd=3)
+
+    in_mult = (1,) + tuple(mult)
+    block_in = hs
+    for lvl in range(len(mult)):
+        block_in = hs * in_mult[lvl]
+        block_out = hs * mult[lvl]
+        for j in range(nrb):
+            res(f"encoder.down.{lvl}.block.{j}", block_in, block_out)
+            block_in = block_out
+        if sdn[lvl]:
+            _conv(sd, f"encoder.down.{lvl}.downsample.conv.conv", block_in, block_in, (1, 3, 3), seed, nd=3)
+    res("encoder.mid.block_1", block_in, block_in)
+    _gn(sd, "encoder.mid.attn_1.norm", block_in, seed)
+    for n in ("q", "k", "v"):
+        _conv(sd, f"encoder.mid.attn_1.{n}.conv", block_in, block_in, 1, seed, nd=3)
+    _conv(sd, "encoder.mid.attn_1.proj_out.conv", block_in, block_in, 1, seed, nd=3, gain=0.5)
+    res("encoder.mid.block_2", block_in, block_in)
+    _gn(sd, "encoder.norm_out", block_in, seed)
+    _conv(sd, "encoder.conv_out.conv", 2 * zc, block_in, 3, seed, nd=3)
+    _conv(sd, "quant_conv.conv", 2 * ed, 2 * zc, 1, seed, nd=3)
+    return sd
+
+
 def vae_weights(cfg=None, seed=1234):
     """CausalVAEModel decoder side (modeling_causalvae.py:151-262,268-320,369).
     Every causal conv is <name>.conv.{weight,bias} (conv.py:90)."""

@@ -85,13 +85,14 @@ def load_vae_decoder_cls():
     from typing import Tuple
     path = os.path.join(REF, "CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py")
     tree = ast.parse(open(path).read())
-    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Decoder"][0]
-    code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("Decoder", "Encoder")]
+    code = compile(ast.Module(body=node, type_ignores=[]), path, "exec")
     mu = importlib.import_module("causalvideovae.model.utils.module_utils")
     ns = dict(nn=nn, torch=torch, Tuple=Tuple, Module=str, Normalize=mods.Normalize,
               nonlinearity=importlib.import_module("causalvideovae.model.modules.ops").nonlinearity,
               resolve_str_to_obj=mu.resolve_str_to_obj)
     exec(code, ns)
+    mods.RefEncoder = ns["Encoder"]
     return ns["Decoder"], mods
 
 

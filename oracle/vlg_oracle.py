@@ -542,6 +542,37 @@ def causal_conv3d(x, w, b, pad_hw):
     return out
 
 
+def conv_nd_general(x, w, b, stride, pads, causal_t=False):
+    """Generic strided conv for the encoders.  x [B,Cin,(T,)H,W]; w [Cout,Cin,(kt,)kh,kw]; stride (st,sh,sw) or (sh,sw);
+    pads per spatial dim ((lo,hi),...) zero; causal_t: replicate frame 0 (kt-1) times in front (conv.py:126-129)."""
+    is3d = x.ndim == 5
+    x = x.astype(F32)
+    if not is3d:
+        x = x[:, :, None]
+        w = w[:, :, None]
+        stride = (1,) + tuple(stride)
+        pads = ((0, 0),) + tuple(pads)
+    kt, kh, kw = w.shape[2:]
+    if causal_t and kt > 1:
+        x = np.concatenate([np.repeat(x[:, :, :1], kt - 1, axis=2), x], axis=2)
+    xp = np.pad(x, ((0, 0), (0, 0)) + tuple(pads))
+    st, sh, sw = stride
+    To = (xp.shape[2] - kt) // st + 1
+    Ho = (xp.shape[3] - kh) // sh + 1
+    Wo = (xp.shape[4] - kw) // sw + 1
+    B, Cin = x.shape[:2]
+    out = np.zeros((B, w.shape[0], To * Ho * Wo), F32)
+    for a in range(kt):
+        for i in range(kh):
+            for j in range(kw):
+                patch = xp[:, :, a:a + (To - 1) * st + 1:st, i:i + (Ho - 1) * sh + 1:sh, j:j + (Wo - 1) * sw + 1:sw]
+                out += np.einsum("oc,bcn->bon", w[:, :, a, i, j].astype(F32), np.ascontiguousarray(patch).reshape(B, Cin, -1), optimize=True)
+    out = out.reshape(B, -1, To, Ho, Wo)
+    if b is not None:
+        out = out + b.reshape(1, -1, 1, 1, 1)
+    return out if is3d else out[:, :, 0]
+
+
 def nearest_up2(x):
     return np.repeat(np.repeat(x, 2, axis=-2), 2, axis=-1)                               # vq_model.py:375
 
@@ -622,6 +653,32 @@ class VQOracle:
     def decode_code(self, code, shape):
         return self.decode(self.get_codebook_entry(code, shape))                         # vq_model.py:52-55
 
+    def encoder(self, x, ch_mult=None):
+        """Encoder.forward (vq_model.py:105-124)."""
+        sd = self.sd
+        ch_mult = ch_mult or self.ch_mult
+        h = conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], 1)
+        nres = len(ch_mult)
+        for li in range(nres):
+            for j in range(self.nrb):
+                h = self._res(f"encoder.conv_blocks.{li}.res.{j}", h)
+                if li == nres - 1:
+                    h = self._attn(f"encoder.conv_blocks.{li}.attn.{j}", h)
+            if li != nres - 1:                                                            # Downsample: pad (0,1,0,1), conv k3 s2 p0 (:390-393)
+                p = f"encoder.conv_blocks.{li}.downsample.conv"
+                h = conv_nd_general(h, sd[p + ".weight"], sd[p + ".bias"], (2, 2), ((0, 1), (0, 1)))
+        h = self._res("encoder.mid.0", h)
+        h = self._attn("encoder.mid.1", h)
+        h = self._res("encoder.mid.2", h)
+        h = swish(group_norm(h, sd["encoder.norm_out.weight"], sd["encoder.norm_out.bias"]))
+        return conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], 1)
+
+    def encode(self, x):
+        """VQModel.encode (vq_model.py:41-45): encoder -> quant_conv -> argmin.  Returns (indices [B*h*w], pre-quant z)."""
+        z = conv2d(self.encoder(x), self.sd["quant_conv.weight"], self.sd["quant_conv.bias"], 0)
+        idx, _ = self.argmin(z)
+        return idx, z
+
 
 # ----------------------------------------------------------------------------
 # video codebook nearest neighbour
@@ -691,6 +748,33 @@ class VAEOracle:
         o = np.einsum("bci,bji->bcj", v, w_).reshape(b, c, t, hh, ww)
         o = self._cc(p + ".proj_out", o, 0)
         return x + o
+
+    def encode_moments(self, x, spatial_down=(True, True, True, False), temporal_down=(False, True, True, False)):
+        """CausalVAEModel.encode up to the posterior parameters (modeling_causalvae.py:382-392; Encoder.forward :127-148)."""
+        sd = self.sd
+        h = self._cc("encoder.conv_in", x, 1)
+        for lvl in range(len(self.mult)):
+            for j in range(self.nrb):
+                h = self._res(f"encoder.down.{lvl}.block.{j}", h)
+            if spatial_down[lvl]:                                                         # SpatialDownsample2x (updownsample.py:62-88)
+                p = f"encoder.down.{lvl}.downsample.conv.conv"
+                h = conv_nd_general(h, sd[p + ".weight"], sd[p + ".bias"], (1, 2, 2), ((0, 0), (0, 1), (0, 1)))
+            if temporal_down[lvl]:                                                        # TimeDownsample2x (updownsample.py:163-180)
+                hp = np.concatenate([np.repeat(h[:, :, :1], 2, axis=2), h], axis=2)
+                To = (hp.shape[2] - 3) // 2 + 1
+                h = np.stack([hp[:, :, 2 * k:2 * k + 3].mean(axis=2, dtype=F32) for k in range(To)], axis=2).astype(F32)
+        h = self._res("encoder.mid.block_1", h)
+        h = self._attn("encoder.mid.attn_1", h)
+        h = self._res("encoder.mid.block_2", h)
+        h = swish(group_norm(h, sd["encoder.norm_out.weight"], sd["encoder.norm_out.bias"]))
+        h = self._cc("encoder.conv_out", h, 1)
+        return self._cc("quant_conv", h, 0)
+
+    @staticmethod
+    def posterior_sample(moments, noise):
+        """DiagonalGaussianDistribution (utils/distrib_utils.py:4-19): mean + exp(0.5 * clamp(logvar, -30, 20)) * noise."""
+        mean, logvar = np.split(moments, 2, axis=1)
+        return (mean + np.exp(F32(0.5) * np.clip(logvar, -30.0, 20.0)) * noise).astype(F32)
 
     def decode(self, z):
         sd = self.sd

@@ -167,6 +167,18 @@ def gold_vq(out):
     for blk in m.decoder.mid:
         h = blk(h)
     out["vq_mid"] = h.numpy()
+    # encode side (vq_model.py:41-45): encoder -> quant_conv -> argmin, 64 px image -> 4x4 codes
+    esd = detweights.vq_encoder_weights()
+    full = m.state_dict()
+    for k, v in esd.items():
+        assert k in full and tuple(full[k].shape) == v.shape, k
+        full[k] = t(v)
+    m.load_state_dict(full)
+    ximg = cases.rng(24).standard_normal((2, 3, 64, 64), dtype=np.float32)
+    hq = m.quant_conv(m.encoder(t(ximg)))
+    out["vq_encode_z"] = hq.numpy()
+    _, _, (_, _, eidx) = m.quantize(hq)
+    out["vq_encode_idx"] = eidx.numpy()
     # argmin incl. engineered ties (two identical codebook rows -> first index wins)
     z = cases.rng(22).standard_normal((2, 8, 6, 6), dtype=np.float32)
     _, _, (_, _, idx) = m.quantize(t(z))
@@ -203,6 +215,18 @@ def gold_vae(out):
     x2 = cases.rng(34).standard_normal((1, 4, 5, 2, 2), dtype=np.float32)
     out["vae_timeup"] = mods.TimeUpsample2x(4, 4)(t(x2)).numpy()
     out["vae_conv_in"] = dec.conv_in(pq(t(z))).numpy()
+    # encode side: Encoder + quant_conv -> posterior parameters (modeling_causalvae.py:382-392), 9 frames x 32 x 32 -> [.,16,3,4,4]
+    esd = detweights.vae_encoder_weights(cfg)
+    enc = mods.RefEncoder(z_channels=cfg["z_channels"], hidden_size=cfg["hidden_size"], hidden_size_mult=cfg["hidden_size_mult"],
+                          attn_resolutions=[], conv_in="CausalConv3d", conv_out="CausalConv3d", attention="AttnBlock3D",
+                          resnet_blocks=("ResnetBlock3D",) * 4, spatial_downsample=("SpatialDownsample2x",) * 3 + ("",),
+                          temporal_downsample=("", "TimeDownsample2x", "TimeDownsample2x", ""), mid_resnet="ResnetBlock3D", dropout=0.0,
+                          resolution=256, num_res_blocks=cfg["num_res_blocks"], double_z=True).eval()
+    enc.load_state_dict({k[len("encoder."):]: t(v) for k, v in esd.items() if k.startswith("encoder.")})
+    qc = mods.CausalConv3d(2 * cfg["z_channels"], 2 * cfg["embed_dim"], 1)
+    qc.load_state_dict({"conv.weight": t(esd["quant_conv.conv.weight"]), "conv.bias": t(esd["quant_conv.conv.bias"])})
+    xv = cases.rng(36).standard_normal((1, 3, 9, 32, 32), dtype=np.float32)
+    out["vae_moments"] = qc(enc(t(xv))).numpy()
     # tiled decode (modeling_causalvae.py:468-570) with toy tile sizes so that a [1,C,5,6,6] latent tiles in t, h and w
     Stub = ref_harness.load_vae_tiling_methods()
     st = Stub()

@@ -171,3 +171,50 @@ def test_videovq_decode(golden, dt):
     E = sd["codebook.embeddings"]
     z = np.moveaxis(E[enc], -1, 1).copy()
     assert (m.encode_indices(torch.from_numpy(z)).cpu().numpy() == enc).all()
+
+
+def test_vq_encode_and_round_trip(golden):
+    """VQModel.encode (encoder -> quant_conv -> argmin) vs the reference; decode_code -> encode is a full tokenizer pass."""
+    import video_llamagen_amd as V
+    g = golden("vq")
+    m = V.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).to("cuda", torch.float32).eval()
+    sd = dict(detweights.vq_weights())
+    sd.update(detweights.vq_encoder_weights())
+    _, skipped = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert skipped == []
+    ximg = cases.rng(24).standard_normal((2, 3, 64, 64), dtype=np.float32)
+    _, _, (_, _, idx) = m.encode(torch.from_numpy(ximg))
+    z = to_np(m.last_z)
+    assert np.abs(z - g["vq_encode_z"]).max() < 2e-3 * np.abs(g["vq_encode_z"]).max()
+    assert (idx.cpu().numpy() == g["vq_encode_idx"]).mean() > 0.9       # near-ties of the 16384-way argmin may flip
+    # pipeline property at a full-size image: encode(decode_code(c)) has the right shape / index range
+    code = cases.rng(25).integers(0, 16384, size=(1, 256)).astype(np.int64)
+    img = m.decode_code(torch.from_numpy(code), [1, 8, 16, 16])
+    _, _, (_, _, idx2) = m.encode(img)
+    assert idx2.shape == (256,) and int(idx2.min()) >= 0 and int(idx2.max()) < 16384
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_vae_encode(golden, dt):
+    import video_llamagen_amd as V
+    g = golden("vae")
+    cfg = cases.TINY_VAE
+    m = V.VAE_models["VAE-16"](hidden_size=cfg["hidden_size"], z_channels=cfg["z_channels"], embed_dim=cfg["embed_dim"],
+                               hidden_size_mult=cfg["hidden_size_mult"], num_res_blocks=cfg["num_res_blocks"])
+    m.to("cuda", torch.float32 if dt == "fp32" else torch.bfloat16)
+    sd = dict(detweights.vae_weights(cfg))
+    sd.update(detweights.vae_encoder_weights(cfg))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    xv = cases.rng(36).standard_normal((1, 3, 9, 32, 32), dtype=np.float32)
+    post = m.encode(torch.from_numpy(xv))
+    ref = g["vae_moments"]
+    mom = to_np(post.parameters)
+    assert mom.shape == ref.shape == (1, 16, 3, 4, 4)
+    tol = 2e-3 if dt == "fp32" else 5e-2
+    assert np.abs(mom - ref).max() < tol * np.abs(ref).max()
+    noise = torch.from_numpy(cases.rng(37).standard_normal((1, 8, 3, 4, 4), dtype=np.float32))
+    zs = to_np(post.sample(noise))
+    if dt == "fp32":
+        np.testing.assert_allclose(zs, O.VAEOracle.posterior_sample(ref, noise.numpy()), atol=5e-3 * np.abs(zs).max())
+    y = m.decode(post.mode())                                     # encode -> decode round trip runs end to end
+    assert tuple(y.shape) == (1, 3, 9, 32, 32)

@@ -205,3 +205,24 @@ def test_videovq_decode(golden):
     y = vq.decode(enc)
     assert y.shape == g["videovq_decode"].shape == (2, 3, 8, 12, 16)
     np.testing.assert_allclose(y, g["videovq_decode"], atol=2e-3 * np.abs(g["videovq_decode"]).max())
+
+
+def test_encoders(golden):
+    """encode side: VQ Encoder -> quant_conv -> argmin; CausalVAE Encoder -> quant_conv -> posterior moments."""
+    g = golden("vq")
+    sd = dict(detweights.vq_weights())
+    sd.update(detweights.vq_encoder_weights())
+    vq = O.VQOracle(sd)
+    ximg = cases.rng(24).standard_normal((2, 3, 64, 64), dtype=np.float32)
+    idx, z = vq.encode(ximg)
+    np.testing.assert_allclose(z, g["vq_encode_z"], atol=2e-3 * np.abs(g["vq_encode_z"]).max())
+    assert (idx == g["vq_encode_idx"]).mean() > 0.9
+    gv = golden("vae")
+    cfg = cases.TINY_VAE
+    vsd = dict(detweights.vae_weights(cfg))
+    vsd.update(detweights.vae_encoder_weights(cfg))
+    vae = O.VAEOracle(vsd, hidden_size=cfg["hidden_size"], hidden_size_mult=cfg["hidden_size_mult"], num_res_blocks=cfg["num_res_blocks"])
+    xv = cases.rng(36).standard_normal((1, 3, 9, 32, 32), dtype=np.float32)
+    mo = vae.encode_moments(xv)
+    assert mo.shape == gv["vae_moments"].shape == (1, 16, 3, 4, 4)
+    np.testing.assert_allclose(mo, gv["vae_moments"], atol=2e-3 * np.abs(gv["vae_moments"]).max())

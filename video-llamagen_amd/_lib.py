@@ -57,6 +57,7 @@ SYMBOLS = [
     "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",
     "vlg_codebook_argmin",
     "vlg_vae_create", "vlg_vae_destroy", "vlg_vae_load_tensor", "vlg_vae_decode", "vlg_vae_out_shape",
+    "vlg_vq_encode", "vlg_vae_encode",
     "vlg_vqvae_create", "vlg_vqvae_destroy", "vlg_vqvae_load_tensor", "vlg_vqvae_decode",
 ]
 

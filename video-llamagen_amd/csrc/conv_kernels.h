@@ -11,6 +11,8 @@ struct ConvDesc {
   int kt, kh, kw;           // kernel; zero pad kh/2, kw/2 in H/W; causal replicate pad (kt-1) frames in front (conv.py:124-130)
   int up;                   // 1: nearest 2x on H and W applied to the input first (vq_model.py:375; updownsample.py:146-153)
   int tmode = 0;            // time padding: 0 = causal replicate (CausalConv3d), 1 = symmetric zero pad (SamePadConv3d, vqvae.py:276-296)
+  int sh = 1;               // spatial stride (1 or 2; encoders' Downsample / SpatialDownsample2x)
+  int ph0 = -1, pw0 = -1;   // leading zero pad in H / W; -1 = kh/2, kw/2 ("same").  Downsample pads (0,1): ph0 = pw0 = 0
 };
 
 // out = conv(in) + bias (+ residual).  w: [Cout][taps][Cin] (re-laid out at load time), bias fp32 [Cout].
@@ -37,6 +39,13 @@ int q12_permute(const T* x, T* y, int B, int T_, int HW, int C, bool inverse, hi
 // TimeUpsample2x (updownsample.py:189-194): [B,T,HW,C] -> [B,2T-1,HW,C]
 template <typename T>
 int time_upsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st);
+
+// TimeDownsample2x (updownsample.py:163-180): replicate frame 0 twice in front, AvgPool3d((3,1,1), stride (2,1,1)): T -> (T-1)/2 + 1
+template <typename T>
+int time_downsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st);
+// [B,P,C] channels-last T -> planar fp32 [B,C,P]
+template <typename T>
+int cl_to_planar_f32(const T* x, float* y, int B, int C, long long P, hipStream_t st);
 
 // ---- tokenizer_video VQ-VAE decoder pieces (tokenizer/tokenizer_video/vqvae.py, attention.py) ----------------------------
 // y = relu(batchnorm_eval(x)) on channels-last data; rm/rv/gamma/beta fp32 [C], eps 1e-5

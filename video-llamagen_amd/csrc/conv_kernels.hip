@@ -49,8 +49,10 @@ __device__ __forceinline__ long long tap_src(const PosDec& pd, const ConvDesc& d
     ti = pd.t + a - ((d.kt - 1) / 2 + (d.kt - 1) % 2);    // SamePadConv3d: zero pad (p//2 + p%2, p//2)
     if (ti < 0 || ti >= d.Ti) return -1;
   }
-  const int uy = pd.y + i - d.kh / 2, ux = pd.x + j - d.kw / 2;
-  if (!pd.ok || uy < 0 || ux < 0 || uy >= d.Ho || ux >= d.Wo) return -1;   // zero pad of nn.Conv (stride 1, "same")
+  const int ph0 = d.ph0 < 0 ? d.kh / 2 : d.ph0, pw0 = d.pw0 < 0 ? d.kw / 2 : d.pw0;
+  const int uy = pd.y * d.sh + i - ph0, ux = pd.x * d.sh + j - pw0;
+  const int He = d.Hi << d.up, We = d.Wi << d.up;                           // extent of the (virtually upsampled) input
+  if (!pd.ok || uy < 0 || ux < 0 || uy >= He || ux >= We) return -1;        // zero padding
   const int iy = uy >> d.up, ix = ux >> d.up;             // nearest 2x upsample folded in
   return ((((long long)pd.b * d.Ti + ti) * d.Hi + iy) * d.Wi + ix) * d.Cin;
 }
@@ -642,6 +644,53 @@ int time_upsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t 
 }
 template int time_upsample2x<float>(const float*, float*, int, int, long long, hipStream_t);
 template int time_upsample2x<bf16>(const bf16*, bf16*, int, int, long long, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void time_down_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, int To, long long HWC, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long e = i % HWC;
+  const long long r = i / HWC;
+  const int to = (int)(r % To);
+  const long long b = r / To;
+  const T* xb = x + b * Tn * HWC + e;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int ti = 2 * to + k - 2;          // two replicated copies of frame 0 in front
+    ti = ti < 0 ? 0 : ti;
+    s += DT<T>::ld(xb + (size_t)ti * HWC);
+  }
+  DT<T>::st(y + i, s / 3.0f);
+}
+template <typename T>
+int time_downsample2x(const T* x, T* y, int B, int T_, long long HWC, hipStream_t st) {
+  const int To = (T_ - 1) / 2 + 1;
+  const long long total = (long long)B * To * HWC;
+  time_down_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, T_, To, HWC, total);
+  return VLG_OK;
+}
+template int time_downsample2x<float>(const float*, float*, int, int, long long, hipStream_t);
+template int time_downsample2x<bf16>(const bf16*, bf16*, int, int, long long, hipStream_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_planar_kernel(const T* __restrict__ x, float* __restrict__ y, int C, long long P, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long r = i / C;
+  const long long p = r % P;
+  const long long b = r / P;
+  y[(b * C + c) * P + p] = DT<T>::ld(x + i);
+}
+template <typename T>
+int cl_to_planar_f32(const T* x, float* y, int B, int C, long long P, hipStream_t st) {
+  const long long total = (long long)B * C * P;
+  cl_to_planar_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(x, y, C, P, total);
+  return VLG_OK;
+}
+template int cl_to_planar_f32<float>(const float*, float*, int, int, long long, hipStream_t);
+template int cl_to_planar_f32<bf16>(const bf16*, float*, int, int, long long, hipStream_t);
 
 template <typename T>
 __global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ x, T* __restrict__ y, int C, long long P, long long total) {

@@ -37,8 +37,7 @@ struct Store {
   bool linear_as_conv = false;   // 2-D nn.Linear weights stored like 1x1 conv weights (tokenizer_video attention)
 
   bool skip(const std::string& n) const {
-    return n.rfind("encoder.", 0) == 0 || n.rfind("quant_conv", 0) == 0 || n.rfind("loss", 0) == 0 ||
-           n.find("codebook_used") != std::string::npos;
+    return n.rfind("loss", 0) == 0 || n.find("codebook_used") != std::string::npos;   // training-only tensors
   }
 
   int load(const char* name, const void* data, const int64_t* shape, int ndim, int src_dtype, int on_dev, int32_t* consumed) {
@@ -132,14 +131,19 @@ struct Net {
 
   int tmode = 0;     // 1: SamePadConv3d (symmetric zero time pad) instead of CausalConv3d
 
-  int conv(const Act& x, const std::string& name, int up, const Act* residual, Act& y, float* planar_out = nullptr) {
+  // stride 2 (encoders): Downsample / SpatialDownsample2x = zero pad (0,1) bottom/right only, conv k3 s2 p0
+  int conv_down2(const Act& x, const std::string& name, Act& y) { return conv(x, name, 0, nullptr, y, nullptr, 2); }
+
+  int conv(const Act& x, const std::string& name, int up, const Act* residual, Act& y, float* planar_out = nullptr, int stride = 1) {
     const Param* w = s.find(name + csuf + ".weight");
     const Param* b = s.find(name + csuf + ".bias");
     VLG_CHECK(w && w->conv, VLG_ERR_STATE, "weight %s%s.weight was never loaded", name.c_str(), csuf.c_str());
     VLG_CHECK(w->shape[1] == x.C, VLG_ERR_BAD_SHAPE, "%s: Cin %lld != activation channels %d", name.c_str(), (long long)w->shape[1], x.C);
     ConvDesc d;
     d.B = x.B; d.Ti = x.T; d.Hi = x.H; d.Wi = x.W; d.Cin = x.C;
-    d.To = x.T; d.Ho = x.H << up; d.Wo = x.W << up; d.Cout = (int)w->shape[0];
+    d.To = x.T; d.Ho = (x.H << up) / stride; d.Wo = (x.W << up) / stride; d.Cout = (int)w->shape[0];
+    d.sh = stride;
+    if (stride == 2) d.ph0 = d.pw0 = 0;
     d.kt = (int)w->shape[2]; d.kh = (int)w->shape[3]; d.kw = (int)w->shape[4];
     d.up = up;
     d.tmode = tmode;
@@ -340,6 +344,7 @@ extern "C" int vlg_codebook_argmin(const float* d_z, const float* d_codebook, in
 struct vlg_vae {
   vlg_vae_config cfg;
   Store s;
+  int enc_time_down[8] = {0, 1, 1, 0, 0, 0, 0, 0};   // encoder_temporal_downsample default ("", TimeDownsample2x x2, "") (:291-296)
 };
 
 extern "C" int vlg_vae_create(const vlg_vae_config* cfg, vlg_vae_t** out) {
@@ -439,6 +444,132 @@ extern "C" int vlg_vae_decode(vlg_vae_t* h, const float* d_z, int32_t B, int32_t
   return vae_decode_impl<float>(h, d_z, B, t, hh, ww, d_out, (hipStream_t)stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// encode side
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int vq_encode_impl(vlg_vq* h, const float* x_planar, int B, int Hh, int Ww, int32_t* idx, float* z_out, hipStream_t st) {
+  Store& s = h->s;
+  s.st = st;
+  s.release_all();
+  Net<T> net{s, st, ""};
+  const Param* E = s.find("quantize.embedding.weight");
+  VLG_CHECK(E, VLG_ERR_STATE, "quantize.embedding.weight was never loaded");
+  const int nres = h->cfg.n_mult;
+  VLG_CHECK(Hh % (1 << (nres - 1)) == 0 && Ww % (1 << (nres - 1)) == 0, VLG_ERR_BAD_SHAPE, "image size must be divisible by %d", 1 << (nres - 1));
+  Act a, b;
+  a.B = B; a.T = 1; a.H = Hh; a.W = Ww; a.C = 3;
+  VLG_TRY(s.get((size_t)a.numel() * sizeof(T), a));
+  VLG_TRY(planar_f32_to_cl<T>(x_planar, (T*)a.p, B, 3, (long long)Hh * Ww, st));
+  VLG_TRY(net.conv(a, "encoder.conv_in", 0, nullptr, b));   // vq_model.py:106
+  s.put(a);
+  a = b;
+  b.slot = -1;
+  for (int li = 0; li < nres; ++li) {                       // :108-114
+    const std::string p = "encoder.conv_blocks." + std::to_string(li);
+    for (int j = 0; j < h->cfg.num_res_blocks; ++j) {
+      VLG_TRY(net.resblock(a, p + ".res." + std::to_string(j), b));
+      if (li == nres - 1) {
+        VLG_TRY(net.attn(b, p + ".attn." + std::to_string(j), false, a));
+      } else {
+        a = b;
+        b.slot = -1;
+      }
+    }
+    if (li != nres - 1) {
+      VLG_TRY(net.conv_down2(a, p + ".downsample.conv", b));
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+  }
+  VLG_TRY(net.resblock(a, "encoder.mid.0", b));
+  VLG_TRY(net.attn(b, "encoder.mid.1", false, a));
+  VLG_TRY(net.resblock(a, "encoder.mid.2", b));
+  VLG_TRY(net.gn(b, "encoder.norm_out", true, a));
+  s.put(b);
+  VLG_TRY(net.conv(a, "encoder.conv_out", 0, nullptr, b));
+  s.put(a);
+  VLG_TRY(net.conv(b, "quant_conv", 0, nullptr, a));          // vq_model.py:43
+  s.put(b);
+  // argmin over the codebook on the channels-last z (fp32 copy for the exact reference arithmetic)
+  Act zf;
+  zf.B = a.B; zf.T = 1; zf.H = a.H; zf.W = a.W; zf.C = a.C;
+  VLG_TRY(s.get((size_t)a.numel() * sizeof(float), zf));
+  const long long P = (long long)a.H * a.W;
+  VLG_TRY(cl_to_planar_f32<T>((const T*)a.p, (float*)zf.p, a.B, a.C, P, st));
+  if (z_out) VLG_HIP(hipMemcpyAsync(z_out, zf.p, (size_t)a.numel() * sizeof(float), hipMemcpyDeviceToDevice, st));
+  VLG_TRY(codebook_argmin((const float*)zf.p, 1, P, P, (long long)a.C * P, E->buf.as<float>(), (long long)a.B * P, h->cfg.codebook_size, a.C,
+                          h->cfg.l2_norm != 0, idx, st));
+  s.put(a);
+  s.put(zf);
+  return VLG_OK;
+}
+
+extern "C" int vlg_vq_encode(vlg_vq_t* h, const float* d_x, int32_t B, int32_t Hh, int32_t Ww, int32_t* d_idx, float* d_z, void* stream) {
+  VLG_CHECK(h && d_x && d_idx && B > 0 && Hh > 0 && Ww > 0, VLG_ERR_BAD_ARG, "vlg_vq_encode: bad argument");
+  if (h->s.dtype == VLG_BF16) return vq_encode_impl<bf16>(h, d_x, B, Hh, Ww, d_idx, d_z, (hipStream_t)stream);
+  return vq_encode_impl<float>(h, d_x, B, Hh, Ww, d_idx, d_z, (hipStream_t)stream);
+}
+
+template <typename T>
+static int vae_encode_impl(vlg_vae* h, const float* x_planar, int B, int Tn, int Hh, int Ww, float* moments, hipStream_t st) {
+  Store& s = h->s;
+  s.st = st;
+  s.release_all();
+  Net<T> net{s, st, ".conv"};
+  Act a, b;
+  a.B = B; a.T = Tn; a.H = Hh; a.W = Ww; a.C = 3;
+  VLG_TRY(s.get((size_t)a.numel() * sizeof(T), a));
+  VLG_TRY(planar_f32_to_cl<T>(x_planar, (T*)a.p, B, 3, a.P(), st));
+  VLG_TRY(net.conv(a, "encoder.conv_in", 0, nullptr, b));     // modeling_causalvae.py:128
+  s.put(a);
+  a = b;
+  b.slot = -1;
+  for (int lvl = 0; lvl < h->cfg.n_mult; ++lvl) {            // :129-140
+    const std::string p = "encoder.down." + std::to_string(lvl);
+    for (int j = 0; j < h->cfg.num_res_blocks; ++j) {
+      VLG_TRY(net.resblock(a, p + ".block." + std::to_string(j), b));
+      a = b;
+      b.slot = -1;
+    }
+    if (s.has(p + ".downsample.conv.conv.weight")) {         // SpatialDownsample2x
+      VLG_CHECK(a.H % 2 == 0 && a.W % 2 == 0, VLG_ERR_BAD_SHAPE, "odd spatial size at encoder level %d", lvl);
+      VLG_TRY(net.conv_down2(a, p + ".downsample.conv", b));
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+    if (lvl < 8 && h->enc_time_down[lvl] && a.T > 1) {       // TimeDownsample2x
+      b = a;
+      b.slot = -1;
+      b.T = (a.T - 1) / 2 + 1;
+      VLG_TRY(s.get((size_t)b.numel() * sizeof(T), b));
+      VLG_TRY(time_downsample2x<T>((const T*)a.p, (T*)b.p, a.B, a.T, (long long)a.H * a.W * a.C, st));
+      s.put(a);
+      a = b;
+      b.slot = -1;
+    }
+  }
+  VLG_TRY(net.resblock(a, "encoder.mid.block_1", b));
+  VLG_TRY(net.attn(b, "encoder.mid.attn_1", true, a));
+  VLG_TRY(net.resblock(a, "encoder.mid.block_2", b));
+  VLG_TRY(net.gn(b, "encoder.norm_out", true, a));
+  s.put(b);
+  VLG_TRY(net.conv(a, "encoder.conv_out", 0, nullptr, b));
+  s.put(a);
+  Act y;
+  VLG_TRY(net.conv(b, "quant_conv", 0, nullptr, y, moments)); // :389
+  s.put(b);
+  return VLG_OK;
+}
+
+extern "C" int vlg_vae_encode(vlg_vae_t* h, const float* d_x, int32_t B, int32_t T_, int32_t Hh, int32_t Ww, float* d_moments, void* stream) {
+  VLG_CHECK(h && d_x && d_moments && B > 0 && T_ > 0 && Hh > 0 && Ww > 0, VLG_ERR_BAD_ARG, "vlg_vae_encode: bad argument");
+  if (h->s.dtype == VLG_BF16) return vae_encode_impl<bf16>(h, d_x, B, T_, Hh, Ww, d_moments, (hipStream_t)stream);
+  return vae_encode_impl<float>(h, d_x, B, T_, Hh, Ww, d_moments, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // tokenizer_video VQ-VAE decode

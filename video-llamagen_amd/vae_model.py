@@ -13,6 +13,25 @@ import torch
 from . import _lib as L
 
 
+class DiagonalGaussianDistribution:
+    """utils/distrib_utils.py:4-42 (mean | logvar along dim 1, logvar clamped to [-30, 20])."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, noise=None):
+        if noise is None:
+            noise = torch.randn(self.mean.shape, device=self.mean.device)
+        return self.mean + self.std * noise.to(self.mean.device)
+
+    def mode(self):
+        return self.mean
+
+
 class CausalVAEModel:
     def __init__(self, hidden_size=128, z_channels=4, hidden_size_mult=(1, 2, 4, 4), attn_resolutions=(), dropout=0.0,
                  resolution=256, double_z=True, embed_dim=4, num_res_blocks=2,
@@ -206,6 +225,26 @@ class CausalVAEModel:
                 result_row.append(tile[:, :, :, :row_limit, :row_limit])
             result_rows.append(torch.cat(result_row, dim=4))
         return torch.cat(result_rows, dim=3)
+
+    @torch.no_grad()
+    def encode(self, x):
+        """x float [B,3,T,H,W] -> DiagonalGaussianDistribution over [B, embed_dim, (T-1)/4+1, H/8, W/8] (modeling_causalvae.py:382-392)."""
+        self._ensure_handle()
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise L.VlgError(-2, "x must be [B,3,T,H,W], got %s" % (tuple(x.shape),))
+        if self.use_tiling and (x.shape[-1] > self.tile_sample_min_size or x.shape[-2] > self.tile_sample_min_size
+                                or x.shape[-3] > self.tile_sample_min_size_t):
+            raise L.VlgError(-3, "tiled_encode is not implemented")
+        B, _, T, H, W = [int(v) for v in x.shape]
+        xf = x.to(device=self._device, dtype=torch.float32).contiguous()
+        n = len(self.config.hidden_size_mult) - 1
+        t = T
+        for _ in range(2):
+            t = (t - 1) // 2 + 1 if t > 1 else t
+        mom = torch.empty((B, 2 * self.config.embed_dim, t, H >> n, W >> n), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().vlg_vae_encode(self._handle, L.ptr(xf), B, T, H, W, L.ptr(mom), L.stream_ptr(self._device)))
+        return DiagonalGaussianDistribution(mom)
 
     def _decode_plain(self, z):
         B, _, t, hh, ww = [int(s) for s in z.shape]

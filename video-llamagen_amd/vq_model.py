@@ -156,6 +156,21 @@ class VQModel:
         return out
 
     @torch.no_grad()
+    def encode(self, x):
+        """VQModel.encode (vq_model.py:41-45): x float [B,3,H,W] in [-1,1] -> (quant [B,C,h,w], (None, None, None, 0),
+        (None, None, indices int32 [B*h*w])).  quant = normalised codebook rows of the indices (the value of z_q, :233,254)."""
+        self._ensure_handle()
+        x = x.to(device=self._device, dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        f = 2 ** (len(self.config.encoder_ch_mult) - 1)
+        idx = torch.empty((B * (H // f) * (W // f),), dtype=torch.int32, device=self._device)
+        z = torch.empty((B, self.config.codebook_embed_dim, H // f, W // f), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().vlg_vq_encode(self._handle, L.ptr(x), B, H, W, L.ptr(idx), L.ptr(z), L.stream_ptr(self._device)))
+        self.last_z = z
+        return None, (None, None, None, 0), (None, None, idx)
+
+    @torch.no_grad()
     def quantize_indices(self, z):
         """min_encoding_indices of VectorQuantizer.forward (vq_model.py:215-233): z float [B, C, H, W] -> int32 [B*H*W]."""
         self._ensure_handle()
