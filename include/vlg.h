@@ -65,7 +65,8 @@ int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out);
 int vlg_gpt_destroy(vlg_gpt_t* h);
 /* State-dict entry by its reference name ("layers.3.attention.wqkv.weight", ...).
  * `data` is fp32 or bf16 (src_dtype), host (src_on_device=0) or device memory; it is converted to the
- * handle dtype and copied.  Unknown names ("freqs_cis", training-only tensors) return VLG_OK with
+ * handle dtype and copied; a device source is read after a device-wide synchronise, so work still
+ * pending on any caller stream that produces it is waited for.  Unknown names ("freqs_cis", training-only tensors) return VLG_OK with
  * *consumed = 0 (strict=False semantics of sample_t2i.py:71).                                   */
 int vlg_gpt_load_tensor(vlg_gpt_t* h, const char* name, const void* data, const int64_t* shape,
                         int32_t ndim, int32_t src_dtype, int32_t src_on_device, int32_t* consumed);

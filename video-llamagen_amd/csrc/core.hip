@@ -25,6 +25,8 @@ int upload_convert(void* dst, int dst_dtype, const void* data, int src_dtype, in
   const size_t sbytes = (size_t)n * dtype_size(src_dtype);
   const void* dsrc = data;
   DevBuf staging;
+  // a device source may still be being produced on a stream this library does not know: loading is not hot, order against everything
+  if (src_on_device) VLG_HIP(hipDeviceSynchronize());
   if (!src_on_device) {
     if (src_dtype == dst_dtype) {
       VLG_HIP(hipMemcpy(dst, data, sbytes, hipMemcpyHostToDevice));
