@@ -13,6 +13,20 @@
 //             EPI_STORE  out = rt(act(rt(acc + bias))) (T and/or fp32)                        (heads, adapters)
 #include "gpt_kernels.h"
 
+#ifdef VLG_KTRACE   // tools/microbench: in-kernel timestamps (100 MHz), thread 0 of every workgroup
+#define VLG_KT(i)                                                                                                        \
+  do {                                                                                                                   \
+    if (threadIdx.x == 0 && fa.trace) {                                                                                  \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
+      fa.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64();    \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define VLG_KT(i) \
+  do {            \
+  } while (0)
+#endif
+
 namespace vlg {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -106,9 +120,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   constexpr int EPV = 16 / sizeof(T);   // elements per 16-byte vector
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y == 2 && (gridDim.x & 7) == 0) {
+    // the two row halves of one n-tile stream the same weight rows: put them on the same XCD (workgroups are dealt to the 8 XCDs
+    // round-robin in linear order) so the second reader hits that XCD's L2.  Speed only.
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    bx = (id & 7) + 8 * (id >> 4);
+    by = (id >> 3) & 1;
+  }
+  const int n0 = bx * 16, m0 = by * (MT * 16);
   const int nkb = K / KBLK;
   const int split = blockIdx.z, splits = gridDim.z;   // > 1 only for !PRO kernels (host-enforced)
+  VLG_KT(0);
 
   __shared__ float red[NW][NH][MT][256];
   __shared__ int ticket_sm;
@@ -131,14 +154,60 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     row = row < M ? row : M - 1;
     xrow[mt] = x + (size_t)row * K;
   }
-  if constexpr (PRO) {
-    const int nvec = K / EPV;
-    if ((int)threadIdx.x < nvec) gsm[threadIdx.x] = reinterpret_cast<const u32x4_t*>(fa.norm_w)[threadIdx.x];
-  }
+  // Request order = arrival order (vmcnt retires in order): activations (L2) first, then the norm weight, then the weight stream
+  // (HBM), then the epilogue operands that do not depend on the GEMM (residual rows; RoPE pair of the current position).  The
+  // norm prologue then runs on the activations while the weights are still in flight, and the epilogue never waits on memory.
+  const int et = threadIdx.x, ee = et >> 6, el = et & 63;
+  const int ecol = n0 + (el & 15);
+  float eres[MT], ecx[MT], ecy[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
+  int epos = 0;
+  if constexpr (EPI == EPI_QKV) epos = fa.state->pos;   // scalar load
+  auto epilogue_operands = [&]() {
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
+        row = row < M ? row : M - 1;
+        eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + (size_t)row * N + ecol);
+      }
+    }
+    if constexpr (EPI == EPI_QKV) {
+      const int D = fa.H * fa.hd;
+      const int d = (ecol % D) % fa.hd;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
+        row = row < M ? row : M - 1;
+        const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
+        ecx[mt] = cp[0];
+        ecy[mt] = cp[1];
+      }
+    }
+  };
 
   u32x4_t a[NB][MT][4], b[NB][NH][4];
+  u32x4_t gld = u32x4_t{0u, 0u, 0u, 0u};
+  bool first = true;
   const int kstride = NW * splits;
   for (int kb0 = split * NW + wave; kb0 < nkb; kb0 += NB * kstride) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kb = kb0 + i * kstride;
+      if (kb < nkb) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK) + q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * 4];
+        }
+      }
+    }
+    if constexpr (PRO) {
+      const int gi = (int)threadIdx.x < K / EPV ? (int)threadIdx.x : 0;
+      gld = reinterpret_cast<const u32x4_t*>(fa.norm_w)[gi];
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int kb = kb0 + i * kstride;
@@ -149,13 +218,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
 #pragma unroll
           for (int s2 = 0; s2 < 4; ++s2) b[i][hf][s2] = __builtin_nontemporal_load(pw + s2 * 4);
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK) + q;
-#pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * 4];
-        }
       }
+    }
+    if (first) {
+      epilogue_operands();
+      first = false;
+    }
+    if constexpr (PRO) {
+      if ((int)threadIdx.x < K / EPV) gsm[threadIdx.x] = gld;   // owners sit in waves < K / (4 * KBLK) <= nkb: always in the loop
     }
     if constexpr (PRO) {
       // host guarantees nkb <= NB * NW: this loop body runs once per wave and holds all of the rows' K range
@@ -190,6 +260,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
         }
     }
   }
+  if (first) epilogue_operands();
   if constexpr (PRO) {
     if (wave >= nkb && q == 0) {   // this wave owns no K block
 #pragma unroll
@@ -222,6 +293,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     }
   }
 
+  VLG_KT(1);
   // ---- cross-wave reduction ----
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf)
@@ -230,6 +302,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][hf][mt][e * 64 + lane] = acc[hf][mt][e];
   __syncthreads();
+  VLG_KT(2);
   const int t = threadIdx.x;
   const int e = t >> 6, l2 = t & 63;
   const int col = n0 + (l2 & 15);
@@ -239,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       // In-launch split-K combine (cdna_hip_programming.md §5 "In-launch split-K reduction"): every K-slice workgroup writes
       // its fp32 tile, releases at agent scope, takes a ticket; the last arriver acquires, sums the slices in slice order
       // (deterministic) and runs the epilogue.  The counter is reset by the last arriver (zeroed once at allocation).
-      const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+      const int tile = by * gridDim.x + bx;
       float* slab = fa.slabs + ((size_t)tile * splits + split) * (MT * 256);
       if (t < 256) {
 #pragma unroll
@@ -293,8 +366,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     }
     if (row >= M) continue;
     if constexpr (EPI == EPI_RESID) {
-      T* hp = reinterpret_cast<T*>(fa.h) + (size_t)row * N + col;
-      DT<T>::st(hp, DT<T>::ld(hp) + DT<T>::rt(s0));
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(s0));
     } else if constexpr (EPI == EPI_SWIGLU) {
       const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
       DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, DT<T>::rt(silu_g(av)) * bv);
@@ -311,13 +383,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       const int sec = col / D, within = col - sec * D;
       const int hh = within / fa.hd, d = within - hh * fa.hd;
       const int bq = row / fa.Tq, tq = row - bq * fa.Tq;
-      const int p = fa.state->pos + tq;
+      const int p = epos + tq;
       const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
       float o = xs;
       if (sec < 2) {
-        const float2 cs = *reinterpret_cast<const float2*>(fa.freqs + ((size_t)p * (fa.hd / 2) + d / 2) * 2);
-        o = (d & 1) ? __fadd_rn(__fmul_rn(xs, cs.x), __fmul_rn(xp, cs.y))    // x1*c + x0*s
-                    : __fsub_rn(__fmul_rn(xs, cs.x), __fmul_rn(xp, cs.y));   // x0*c - x1*s
+        const float cx = ecx[mt], cy = ecy[mt];
+        o = (d & 1) ? __fadd_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy))    // x1*c + x0*s
+                    : __fsub_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy));   // x0*c - x1*s
       }
       T* dst;
       if (sec == 0)
@@ -327,6 +399,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       DT<T>::st(dst, o);
     }
   }
+  VLG_KT(3);
 }
 
 template <typename T, int MT, int NW, bool PRO>
@@ -362,9 +435,14 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
     set_error("gemm_fused: shape M=%d N=%d K=%d pro=%d epi=%d not covered", M, N, K, (int)pro, epi);
     return VLG_ERR_UNSUPPORTED;
   }
-  const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
+  int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   const int nh = epi == EPI_SWIGLU ? 2 : 1;
-  const bool wide = (mt * nh >= 4);   // NB = 2 -> 8 waves so a workgroup still covers 16 K blocks
+  const int nkb_all = K / KB<T>::KBLK;
+  // few n-tiles (N = D: wo, w2): 16-row workgroups, so twice the CUs stream and each pulls half the activations through its
+  // vector-memory pipe (the row halves of a tile share an XCD, see the kernel); 8 waves when K needs more than 16 K-block slots
+  const bool rows16 = !pro && epi == EPI_RESID && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0 && !(fa.slabs && fa.counters);
+  if (rows16) mt = 1;
+  const bool wide = (mt * nh >= 4) || (rows16 && nkb_all > 16);   // 8 waves so one pass of the K loop covers the whole K range
   int splits = 1;
   if (!pro && (epi == EPI_RESID || epi == EPI_STORE) && fa.slabs && fa.counters) {
     // few n-tiles (N = D): split K over workgroups so every CU streams weights; combined in-launch by the last arriver
@@ -394,7 +472,10 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
     else
       VLG_GF(2, 4);
   } else {
-    VLG_GF(1, 4);
+    if (wide)
+      VLG_GF(1, 8);
+    else
+      VLG_GF(1, 4);
   }
 #undef VLG_GF
   return VLG_OK;

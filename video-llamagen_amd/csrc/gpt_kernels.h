@@ -43,6 +43,9 @@ struct FusedGemm {
   float* slabs = nullptr;
   int* counters = nullptr;
   int max_tiles = 0;
+#ifdef VLG_KTRACE
+  unsigned long long* trace = nullptr;   // tools/microbench only: 4 timestamps per workgroup
+#endif
 };
 template <typename T>
 bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
