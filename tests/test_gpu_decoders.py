@@ -218,3 +218,19 @@ def test_vae_encode(golden, dt):
         np.testing.assert_allclose(zs, O.VAEOracle.posterior_sample(ref, noise.numpy()), atol=5e-3 * np.abs(zs).max())
     y = m.decode(post.mode())                                     # encode -> decode round trip runs end to end
     assert tuple(y.shape) == (1, 3, 9, 32, 32)
+
+
+def test_decoders_are_run_to_run_deterministic():
+    """No result-affecting atomics anywhere on the decode path (GroupNorm statistics are reduced in a fixed order): the same ids /
+    latents decode to bit-identical pixels on repeated calls and on a second handle with the same weights."""
+    import video_llamagen_amd as V
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 16384, (2, 256), generator=g).cuda()
+    vq = [V.VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).to("cuda").eval().init_random_weights(seed=1) for _ in range(2)]
+    a = vq[0].decode_code(ids, [2, 8, 16, 16])
+    assert torch.equal(a, vq[0].decode_code(ids, [2, 8, 16, 16])) and torch.equal(a, vq[1].decode_code(ids, [2, 8, 16, 16]))
+    vae = V.VAE_models["VAE-16"](embed_dim=8).to("cuda", torch.bfloat16).eval()
+    vae.init_random_weights(seed=3)
+    z = torch.randn(1, 8, 2, 16, 16, generator=g).cuda()
+    b = vae.decode(z)
+    assert torch.equal(b, vae.decode(z)) and torch.isfinite(b.float()).all()

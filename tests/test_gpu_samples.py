@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -19,9 +20,14 @@ def test_sample_c2i(tmp_path):
     out = str(tmp_path / "c2i")
     sample_c2i.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="c2i", cls_token_num=1, precision="bf16", vq_model="VQ-16", vq_ckpt=None,
                         codebook_size=16384, codebook_embed_dim=8, image_size=256, downsample_size=16, num_classes=1000, cfg_scale=4.0,
-                        cfg_interval=-1, seed=0, top_k=2000, temperature=1.0, top_p=1.0, num_samples=2, out=out))
+                        cfg_interval=-1, seed=0, top_k=2000, temperature=1.0, top_p=1.0, num_samples=2, out=out, serve=False))
     img = np.load(out + ".npy")
     assert img.shape == (2, 256, 256, 3) and img.dtype == np.uint8 and img.std() > 0
+    # the same run through the request front-end (serve/sample_c2i.py) gives the same images
+    sample_c2i.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="c2i", cls_token_num=1, precision="bf16", vq_model="VQ-16", vq_ckpt=None,
+                        codebook_size=16384, codebook_embed_dim=8, image_size=256, downsample_size=16, num_classes=1000, cfg_scale=4.0,
+                        cfg_interval=-1, seed=0, top_k=2000, temperature=1.0, top_p=1.0, num_samples=2, out=out + "_serve", serve=True))
+    assert np.array_equal(np.load(out + "_serve.npy"), img)
 
 
 def test_sample_t2i_and_t2v(tmp_path):
@@ -38,3 +44,32 @@ def test_sample_t2i_and_t2v(tmp_path):
                         cfg_scale=1.0, seed=0, num_samples=2, out=out))
     vid = np.load(out + ".npy")
     assert vid.shape == (2, 5, 64, 64, 3) and vid.dtype == np.uint8      # 2 latent frames -> 2T-1 = 3 -> 5 frames
+
+
+def test_serve_llm_matches_generate():
+    """serve/sample_c2i.py calling convention: 2B prompts under guidance, outputs in request order, same ids as generate()."""
+    import types
+    import video_llamagen_amd as V
+    args = types.SimpleNamespace(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="c2i", cfg_scale=4.0, precision="bf16", image_size=64,
+                                 downsample_size=16, num_classes=1000, cls_token_num=1)
+    llm = V.LLM(args=args, model="autoregressive/serve/fake_json/GPT-B.json", seed=5, max_num_seqs=6)
+    labels = [207, 360, 387, 974, 88]
+    sp = V.SamplingParams(temperature=1.0, top_p=1.0, top_k=2000, max_tokens=16, seed=11)
+    outs = llm.generate(prompt_token_ids=[[c] for c in labels] + [[1000]] * len(labels), sampling_params=sp, use_tqdm=False)
+    assert [int(o.request_id) for o in outs] == list(range(10)) and all(o.finished for o in outs)
+    ids = torch.tensor([o.outputs[0].token_ids for o in outs])
+    assert ids.shape == (10, 16) and torch.equal(ids[:5], ids[5:])                     # sampler.py:106-108
+    m = llm.llm_engine.model
+    c = torch.tensor(labels, device="cuda")
+    # max_num_seqs 6 -> waves of 3 pairs then 2 pairs; an explicit seed is used by every wave
+    ref = torch.cat([V.generate(m, c[:3], 16, cfg_scale=4.0, temperature=1.0, top_k=2000, top_p=1.0, seed=11),
+                     V.generate(m, c[3:], 16, cfg_scale=4.0, temperature=1.0, top_k=2000, top_p=1.0, seed=11)]).cpu()
+    assert torch.equal(ids[:5], ref.long())
+    # no guidance, greedy (temperature 0), top_k -1
+    args.cfg_scale = 1.0
+    llm2 = V.LLM(args=args, model="GPT-B", seed=5)
+    outs = llm2.generate(prompt_token_ids=[[c] for c in labels], sampling_params=V.SamplingParams(temperature=0.0, max_tokens=8), use_tqdm=False)
+    ref = V.generate(llm2.llm_engine.model, c, 8, sample_logits=False).cpu()
+    assert torch.equal(torch.tensor([o.outputs[0].token_ids for o in outs]), ref.long())
+    with pytest.raises(ValueError):
+        llm2.generate(prompts=["a cat"], sampling_params=sp)

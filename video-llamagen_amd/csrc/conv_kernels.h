@@ -22,7 +22,9 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
                  float* out_planar, hipStream_t st);
 
 // GroupNorm(32 groups, eps) statistics + apply (+ swish) on channels-last data (vq_model.py:354-364, normalize.py:14-17)
-// stats: double [B][32][2] scratch (zeroed inside).
+// stats: scratch of group_norm_scratch_bytes(B, P) bytes.  Statistics are reduced in a fixed order (no atomics): deterministic.
+constexpr int kGnPosPerBlock = 512;
+size_t group_norm_scratch_bytes(int B, long long P);
 template <typename T>
 int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
                bool swish, hipStream_t st);

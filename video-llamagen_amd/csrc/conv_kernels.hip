@@ -248,20 +248,19 @@ template int conv_forward<bf16>(const ConvDesc&, const bf16*, const bf16*, const
 
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups) + optional swish, channels-last
-//   thread -> fixed 8-channel vector (cv = tid % (C/8)), sweeps positions; per-group fp32 partials in LDS, one double
-//   atomicAdd per (workgroup, group) into stats[b][g][{sum, sumsq}].
+//   thread -> fixed VW-channel vector (cv = tid % (C/VW)), sweeps positions; the workgroup's per-group partials are summed in a
+//   fixed order (LDS, no atomics) and written to part[b][block][g][{sum, sumsq}]; gn_finalize_kernel adds the blocks in block
+//   order.  Results do not depend on scheduling: two runs are bit-identical.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int VW>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, long long P, int C,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, long long P, int C,
                                                        int pos_per_block) {
-  __shared__ float sm[32][2];
+  __shared__ float sm[2][256][VW + 1];
   const int b = blockIdx.y;
   const int nvec = C / VW;                // vectors per position
   const int lanes_p = 256 / nvec;         // positions handled in parallel
   const int cv = threadIdx.x % nvec, pl = threadIdx.x / nvec;
   const int cg = C / 32;
-  if (threadIdx.x < 64) sm[threadIdx.x >> 1][threadIdx.x & 1] = 0.f;
-  __syncthreads();
   float s[VW], q[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) s[e] = q[e] = 0.f;
@@ -277,15 +276,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         q[e] += v * v;
       }
     }
+  }
 #pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      const int g = (cv * VW + e) / cg;
-      atomicAdd(&sm[g][0], s[e]);
-      atomicAdd(&sm[g][1], q[e]);
-    }
+  for (int e = 0; e < VW; ++e) {
+    sm[0][threadIdx.x][e] = s[e];
+    sm[1][threadIdx.x][e] = q[e];
   }
   __syncthreads();
-  if (threadIdx.x < 64) atomicAdd(&stats[((size_t)b * 32 + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)], (double)sm[threadIdx.x >> 1][threadIdx.x & 1]);
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x >> 1, comp = threadIdx.x & 1;
+    double tot = 0.0;
+    for (int l = 0; l < lanes_p; ++l)
+      for (int c = g * cg; c < (g + 1) * cg; ++c) tot += (double)sm[comp][l * nvec + c / VW][c % VW];
+    part[(((size_t)b * gridDim.x + blockIdx.x) * 32 + g) * 2 + comp] = tot;
+  }
+}
+
+// stats[b][g][{sum, sumsq}] = sum over blocks of part[b][block][g][.], in block order (4 interleaved chains, then a fixed tree)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+  __shared__ double sm[4][64];
+  const int b = blockIdx.x, j = threadIdx.x & 63, c = threadIdx.x >> 6;
+  double tot = 0.0;
+  for (int k = c; k < nblk; k += 4) tot += part[((size_t)b * nblk + k) * 64 + j];
+  sm[c][j] = tot;
+  __syncthreads();
+  if (c == 0) stats[(size_t)b * 64 + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
 }
 
 template <typename T, int VW>
@@ -315,6 +330,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+size_t group_norm_scratch_bytes(int B, long long P) { return (size_t)B * 64 * sizeof(double) * (1 + (size_t)cdiv64(P, kGnPosPerBlock)); }
+
 template <typename T>
 int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
                bool swish, hipStream_t st) {
@@ -322,19 +339,18 @@ int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* 
     set_error("group_norm: C=%d not divisible by 32 groups", C);
     return VLG_ERR_BAD_SHAPE;
   }
-  hipError_t e = hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * sizeof(double), st);
-  if (e != hipSuccess) {
-    set_error("hipMemsetAsync: %s", hipGetErrorString(e));
-    return VLG_ERR_HIP;
-  }
-  const int ppb = 512;
-  dim3 g1((unsigned)cdiv64(P, ppb), B);
+  const int ppb = kGnPosPerBlock;
+  const int nblk = (int)cdiv64(P, ppb);
+  dim3 g1((unsigned)nblk, B);
+  double* part = stats + (size_t)B * 64;   // scratch layout: [B][64] finals, then [B][nblk][64] per-block partials
   if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
-    gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, stats, P, C, ppb);
+    gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
+    gn_finalize_kernel<<<B, 256, 0, st>>>(part, stats, nblk);
     dim3 g2((unsigned)cdiv64(P * (C / 8), 256), B);
     gn_apply_kernel<T, 8><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
   } else if (C <= 256 && 256 % C == 0) {
-    gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, stats, P, C, ppb);
+    gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
+    gn_finalize_kernel<<<B, 256, 0, st>>>(part, stats, nblk);
     dim3 g2((unsigned)cdiv64(P * C, 256), B);
     gn_apply_kernel<T, 1><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
   } else {

@@ -162,7 +162,7 @@ struct Net {
     y = x;
     y.slot = -1;
     VLG_TRY(s.get((size_t)x.numel() * sizeof(T), y));
-    VLG_TRY(s.stats.reserve((size_t)x.B * 64 * sizeof(double)));
+    VLG_TRY(s.stats.reserve(group_norm_scratch_bytes(x.B, x.P())));
     return group_norm<T>((const T*)x.p, (T*)y.p, g->buf.as<float>(), b->buf.as<float>(), s.stats.as<double>(), x.B, x.P(), x.C, 1e-6f,
                          swish, st);
   }

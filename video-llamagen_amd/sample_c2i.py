@@ -30,10 +30,25 @@ def main(args):
     c_indices = torch.tensor(class_labels, device=device)
     n = len(class_labels)
 
+    llm = None
+    if args.serve:            # autoregressive/serve/sample_c2i.py:33-66: the request front-end instead of a direct generate() call
+        del gpt_model
+        llm = V.LLM(args=args, model=args.gpt_model, seed=2, device=device)
+        print("gpt model:", llm.weights)
+
+    def run_serve(c):
+        prompt_token_ids = [[int(ci)] for ci in c.tolist()]
+        if args.cfg_scale > 1.0:
+            prompt_token_ids.extend([[args.num_classes] for _ in range(len(prompt_token_ids))])
+        sp = V.SamplingParams(temperature=args.temperature, top_p=args.top_p, top_k=args.top_k if args.top_k > 0 else -1,
+                              max_tokens=latent_size ** 2, seed=args.seed)
+        outputs = llm.generate(prompt_token_ids=prompt_token_ids, sampling_params=sp, use_tqdm=False)
+        return torch.tensor([o.outputs[0].token_ids for o in outputs], device=device)[:len(c)]
+
     def run(c):
         qzshape = [len(c), args.codebook_embed_dim, latent_size, latent_size]
         with Timer("gpt sampling"):
-            index_sample = V.generate(gpt_model, c, latent_size ** 2, cfg_scale=args.cfg_scale, cfg_interval=args.cfg_interval,
+            index_sample = run_serve(c) if args.serve else V.generate(gpt_model, c, latent_size ** 2, cfg_scale=args.cfg_scale, cfg_interval=args.cfg_interval,
                                       temperature=args.temperature, top_k=args.top_k, top_p=args.top_p, sample_logits=True, seed=args.seed)
         with Timer("decoder"):
             return vq_model.decode_code(index_sample, qzshape)          # [-1, 1]
@@ -66,4 +81,5 @@ if __name__ == "__main__":
     p.add_argument("--top-p", type=float, default=1.0)
     p.add_argument("--num-samples", type=int, default=8)
     p.add_argument("--out", type=str, default="sample_c2i")
+    p.add_argument("--serve", action="store_true", help="go through the LLM/SamplingParams request front-end (serve/sample_c2i.py)")
     main(p.parse_args())

@@ -1,0 +1,225 @@
+"""Request-level serving front-end over the same decode kernels.
+
+Counterpart of the reference's `autoregressive/serve/` (a patched vLLM 0.4.1: llm.py:20-267 `LLM`, llm_engine.py `LLMEngine.add_request/step`,
+sampler.py:46-125 classifier-free guidance inside the sampler, sample_c2i.py:33-66 the calling convention).  The call surface is kept:
+
+    llm = LLM(args=args, model="GPT-XL")                       # args: gpt_model / gpt_ckpt / cfg_scale / precision / ... (sample_c2i.py:72-95)
+    sp = SamplingParams(temperature=1.0, top_p=1.0, top_k=2000, max_tokens=latent_size ** 2)
+    outs = llm.generate(prompt_token_ids=[[c] for c in labels] + [[1000]] * len(labels), sampling_params=sp, use_tqdm=False)
+    ids = [o.outputs[0].token_ids for o in outs]
+
+Scheduling.  Every request of this workload produces exactly `max_tokens` tokens and stops, so iteration-level ("continuous") batching
+has nothing to reclaim inside a batch: sequences that start together end together.  The scheduler therefore works on WAVES: `step()`
+takes up to `max_num_seqs` waiting requests with identical sampling parameters, runs them through `vlg_gpt_generate` as one batch (KV
+cache sized for the wave, one hipGraph per decode step) and finishes them all; requests that arrived meanwhile join the next wave.
+Per-row positions inside one batch (a request joining mid-flight) are not implemented and would only matter for mixed `max_tokens`.
+
+Classifier-free guidance follows sampler.py:54-58,106-108: with `args.cfg_scale > 1` the second half of the prompts are the null-class
+rows; logits are combined `u + (c - u) * s`, one token is drawn per pair and written to both members.  Here the pair shares one row of
+the user batch (the engine doubles it internally), and both requests of the pair report the same token ids.
+
+The sampling filter is the eager path's (generate.py:16-54); it coincides with vLLM's `_apply_top_k_top_p` for `top_p = 1` (the
+setting of serve/sample_c2i.py) — top-k keeps ties in both.
+"""
+import collections
+import dataclasses
+import time
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from .generate import generate as _generate
+from .gpt import GPT_models
+from .sample_common import load_or_init
+
+
+@dataclasses.dataclass(frozen=True)
+class SamplingParams:
+    """The subset of vllm.SamplingParams the reference's script sets (sample_c2i.py:47-49) plus a seed."""
+    temperature: float = 1.0
+    top_p: float = 1.0
+    top_k: int = -1            # -1 = all tokens (vLLM convention)
+    max_tokens: int = 16
+    seed: Optional[int] = None
+
+    def __post_init__(self):
+        if self.temperature < 0:
+            raise ValueError(f"temperature must be non-negative, got {self.temperature}.")
+        if not 0.0 < self.top_p <= 1.0:
+            raise ValueError(f"top_p must be in (0, 1], got {self.top_p}.")
+        if self.top_k < -1 or self.top_k == 0:
+            raise ValueError(f"top_k must be -1 (disable), or at least 1, got {self.top_k}.")
+        if self.max_tokens < 1:
+            raise ValueError(f"max_tokens must be at least 1, got {self.max_tokens}.")
+
+
+@dataclasses.dataclass
+class CompletionOutput:
+    index: int
+    token_ids: List[int]
+    text: str = ""
+    finish_reason: Optional[str] = "length"
+
+
+@dataclasses.dataclass
+class RequestOutput:
+    request_id: str
+    prompt: Optional[str]
+    prompt_token_ids: List[int]
+    outputs: List[CompletionOutput]
+    finished: bool = True
+
+
+@dataclasses.dataclass
+class _Request:
+    request_id: str
+    prompt_token_ids: List[int]
+    params: SamplingParams
+    arrival: float
+
+
+class Scheduler:
+    """FIFO wave scheduler (host logic only; unit-tested on CPU).  A wave = requests with equal SamplingParams, at most
+    `max_num_seqs` of them; with guidance a wave holds whole (cond, uncond) pairs, `max_num_seqs` counting both members
+    (the reference feeds 2B prompts for B images, sample_c2i.py:35-37)."""
+
+    def __init__(self, max_num_seqs=256, cfg=False, null_token=None):
+        if max_num_seqs < (2 if cfg else 1):
+            raise ValueError("max_num_seqs too small")
+        self.max_num_seqs = max_num_seqs
+        self.cfg = cfg
+        self.null_token = null_token
+        self.waiting = collections.deque()
+
+    def add(self, req):
+        self.waiting.append(req)
+
+    def __len__(self):
+        return len(self.waiting)
+
+    def _is_null(self, req):
+        return self.cfg and len(req.prompt_token_ids) == 1 and req.prompt_token_ids[0] == self.null_token
+
+    def next_wave(self):
+        """-> (cond requests, partner uncond requests or None per cond).  Requests stay queued when their partner has not arrived."""
+        if not self.waiting:
+            return [], []
+        head = self.waiting[0].params
+        same = [r for r in self.waiting if r.params == head]
+        if not self.cfg:
+            wave = same[:self.max_num_seqs]
+            for r in wave:
+                self.waiting.remove(r)
+            return wave, [None] * len(wave)
+        conds = [r for r in same if not self._is_null(r)]
+        nulls = [r for r in same if self._is_null(r)]
+        n = min(len(conds), len(nulls), self.max_num_seqs // 2)
+        if n == 0:
+            raise ValueError("classifier-free guidance needs one null-class prompt [[%s]] per conditional prompt (sample_c2i.py:36-37)"
+                             % self.null_token)
+        conds, nulls = conds[:n], nulls[:n]          # i-th conditional pairs with the i-th null prompt, in arrival order
+        for r in conds + nulls:
+            self.waiting.remove(r)
+        return conds, nulls
+
+
+class LLMEngine:
+    """add_request / step / has_unfinished_requests, as llm_engine.py exposes them to llm.py:222-260."""
+
+    def __init__(self, model, cfg_scale=1.0, cfg_interval=-1, max_num_seqs=256, seed=0):
+        self.model = model
+        self.cfg_scale = float(cfg_scale)
+        self.cfg_interval = cfg_interval
+        self.seed = seed
+        self.scheduler = Scheduler(max_num_seqs, cfg=self.cfg_scale > 1.0, null_token=getattr(model, "num_classes", None))
+        self.waves_run = 0
+
+    def add_request(self, request_id, prompt, sampling_params, prompt_token_ids=None, **_):
+        if prompt_token_ids is None:
+            raise ValueError("prompt_token_ids is required (skip_tokenizer_init=True, sample_c2i.py:43)")
+        if self.model.model_type == "c2i" and len(prompt_token_ids) != 1:
+            raise ValueError("class-conditional prompts hold exactly one class id")
+        self.scheduler.add(_Request(str(request_id), list(prompt_token_ids), sampling_params or SamplingParams(), time.time()))
+
+    def get_num_unfinished_requests(self):
+        return len(self.scheduler)
+
+    def has_unfinished_requests(self):
+        return len(self.scheduler) > 0
+
+    def step(self) -> List[RequestOutput]:
+        conds, nulls = self.scheduler.next_wave()
+        if not conds:
+            return []
+        sp = conds[0].params
+        dev = self.model._device
+        if self.model.model_type != "c2i":
+            raise NotImplementedError("the serving front-end covers class-conditional prompts (serve/sample_c2i.py is the only caller)")
+        c_indices = torch.tensor([r.prompt_token_ids[0] for r in conds], device=dev, dtype=torch.long)
+        seed = sp.seed if sp.seed is not None else self.seed + self.waves_run
+        ids = _generate(self.model, c_indices, sp.max_tokens, cfg_scale=self.cfg_scale, cfg_interval=self.cfg_interval,
+                        temperature=sp.temperature, top_k=0 if sp.top_k == -1 else sp.top_k, top_p=sp.top_p,
+                        sample_logits=sp.temperature > 0, seed=seed)
+        self.waves_run += 1
+        rows = ids.cpu().tolist()
+        outs = []
+        for r, row in zip(conds, rows):
+            outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, row)]))
+        for r, row in zip(nulls, rows):
+            if r is not None:                          # sampler.py:106-108: the unconditional member repeats its partner's tokens
+                outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, list(row))]))
+        return outs
+
+
+class LLM:
+    """llm.py:20-267.  `model` names the GPT size ("GPT-XL" or a path ending in "GPT-XL.json", the reference's fake_json convention);
+    `args` carries gpt_ckpt / gpt_type / cfg_scale / precision / image_size / downsample_size / num_classes / cls_token_num / from_fsdp."""
+
+    def __init__(self, args, model, skip_tokenizer_init=True, seed=0, gpu_memory_utilization=0.9, max_num_seqs=256, dtype="auto",
+                 device="cuda", **kwargs):
+        name = model.split("/")[-1]
+        name = name[:-5] if name.endswith(".json") else name
+        if name not in GPT_models:
+            raise ValueError("unknown GPT model %r" % model)
+        precision = {"none": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[getattr(args, "precision", "bf16")]
+        if precision is torch.float16:
+            raise ValueError("fp16 is not supported: the engine computes in bf16 or fp32")
+        latent = getattr(args, "image_size", 384) // getattr(args, "downsample_size", 16)
+        gpt = GPT_models[name](block_size=latent ** 2, num_classes=getattr(args, "num_classes", 1000),
+                               cls_token_num=getattr(args, "cls_token_num", 1), model_type=getattr(args, "gpt_type", "c2i"))
+        gpt = gpt.to(device=device, dtype=precision)
+        self.weights = load_or_init(gpt, getattr(args, "gpt_ckpt", None), seed)
+        gpt.eval()
+        self.llm_engine = LLMEngine(gpt, cfg_scale=getattr(args, "cfg_scale", 1.0), cfg_interval=getattr(args, "cfg_interval", -1),
+                                    max_num_seqs=max_num_seqs, seed=seed)
+        self._counter = 0
+
+    def generate(self, prompts=None, sampling_params: Optional[Union[SamplingParams, List[SamplingParams]]] = None,
+                 prompt_token_ids: Optional[List[List[int]]] = None, use_tqdm=True, **_) -> List[RequestOutput]:
+        if prompts is not None:
+            raise ValueError("prompts must be None if skip_tokenizer_init is True")            # llm.py:176-179
+        if prompt_token_ids is None:
+            raise ValueError("Either prompts or prompt_token_ids must be provided.")             # llm.py:173-175
+        n = len(prompt_token_ids)
+        if sampling_params is None:
+            sampling_params = SamplingParams()
+        elif isinstance(sampling_params, list) and len(sampling_params) != n:
+            raise ValueError("The lengths of prompts and sampling_params must be the same.")     # llm.py:199-202
+        for i in range(n):
+            sp = sampling_params[i] if isinstance(sampling_params, list) else sampling_params
+            self.llm_engine.add_request(str(self._counter), None, sp, prompt_token_ids[i])
+            self._counter += 1
+        return self._run_engine(use_tqdm)
+
+    def _run_engine(self, use_tqdm) -> List[RequestOutput]:
+        outputs: Dict[str, RequestOutput] = {}
+        total = self.llm_engine.get_num_unfinished_requests()
+        t0, toks = time.time(), 0
+        while self.llm_engine.has_unfinished_requests():
+            for out in self.llm_engine.step():
+                outputs[out.request_id] = out
+                toks += len(out.outputs[0].token_ids)
+            if use_tqdm:
+                print("Processed prompts: %d/%d, Generation Speed: %.2f toks/s" % (len(outputs), total, toks / max(time.time() - t0, 1e-9)),
+                      flush=True)
+        return sorted(outputs.values(), key=lambda x: int(x.request_id))                          # llm.py:263-266
