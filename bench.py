@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="batch lanes inside generate (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of HIP-graph replay")
+    ap.add_argument("--attn-inlaunch", action="store_true", help="merge the split-KV partials inside the attention launch (slower)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +116,7 @@ def main():
     gpt = build_gpt(V, a, device)
     gpt.lanes = a.lanes
     gpt.use_graph = not a.no_graph
+    gpt.attn_inlaunch = a.attn_inlaunch
     cond, mask = synth_cond(B, device, seed=1 + rank)
     vae = None
     if not a.no_vae and full:

@@ -420,6 +420,9 @@ def test_full_width_decode_paths_agree():
     a = V.generate_t2v(m, cond, 40, mask)
     b = V.generate_t2v(m, cond, 40, mask)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+    m.attn_inlaunch = True             # split-KV partials merged by the last-arriving workgroup: same arithmetic, same order
+    assert torch.equal(a, V.generate_t2v(m, cond, 40, mask))
+    m.attn_inlaunch = False
     m.fuse_gemm = False
     c = V.generate_t2v(m, cond, 40, mask)
     m.fuse_qkv = True

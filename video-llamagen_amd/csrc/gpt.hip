@@ -19,7 +19,7 @@
 using namespace vlg;
 
 struct Lane {
-  DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
+  DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x;   // DiffLoss head
   DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
   hipStream_t st = nullptr;
@@ -57,6 +57,8 @@ struct vlg_gpt {
   hipStream_t s_int = nullptr;   // weight uploads
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
   bool use_graph = true;
+  bool attn_inlaunch = false;        // split-KV partials merged by the last-arriving workgroup instead of a combine launch
+                                     // (r01: 22.96 s vs 21.81 s/step - the ticket's round trip stalls every workgroup's exit)
   bool splitk_inlaunch = false;      // residual GEMMs: K split over workgroups, combined in-launch by the last arriver
   bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
@@ -347,6 +349,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->fuse_gemm = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "attn_inlaunch")) {
+    h->attn_inlaunch = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "fuse_swiglu")) {
     h->fuse_swiglu = value != 0;
     return VLG_OK;
@@ -397,6 +403,7 @@ struct Runner {
   const float* mask;   // device [B, Tc] (lane slice) or null
   int ev_slot = -1;    // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
   StepState* state() { return ln->state.as<StepState>(); }
+  int* attn_cnt() { return h->attn_inlaunch ? ln->attn_cnt.as<int>() : nullptr; }
   template <typename U>
   const U* W(const std::string& n) {
     return reinterpret_cast<const U*>(h->W(n));
@@ -430,7 +437,7 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>()));
+                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt()));
       VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
@@ -484,7 +491,7 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
-                           st, e0, e1));
+                           st, e0, e1, nullptr, 0, nullptr, attn_cnt()));
       FusedGemm fr;
       fr.h = x;
       if (h->splitk_inlaunch) {   // measured r01: the release/acquire pair costs more than the idle CUs (22.9 s vs 22.6 s/step)
@@ -684,6 +691,10 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
   }
   VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
+  if (ln.attn_cnt.bytes < (size_t)M * H * sizeof(int)) {   // arrival counters: zero once, every launch leaves them zero
+    VLG_TRY(ln.attn_cnt.reserve((size_t)M * H * sizeof(int)));
+    VLG_HIP(hipMemset(ln.attn_cnt.p, 0, ln.attn_cnt.bytes));
+  }
   VLG_TRY(ln.x.reserve((size_t)M * D * e));
   VLG_TRY(ln.xn.reserve((size_t)M * D * e));
   VLG_TRY(ln.q.reserve((size_t)M * D * e));
@@ -923,6 +934,7 @@ extern "C" int vlg_attn_decode(const void* d_q, const void* d_k, const void* d_v
     VLG_TRY(s.aux.reserve(attn_ws_floats(Bp, H, hd) * sizeof(float)));
     VLG_TRY(s.state.reserve(sizeof(StepState)));
   }
+
   VLG_TRY(set_state(s.state.as<StepState>(), pos, 0, st));
   if (dtype == VLG_BF16)
     return attn_rows<bf16>((const bf16*)d_q, (bf16*)d_k, (bf16*)d_v, (bf16*)d_out, s.aux.as<float>(), s.state.as<StepState>(),

@@ -81,7 +81,10 @@ template <typename T>
 int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, const StepState* state,
               int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,  // ev0/ev1 bracket the split-KV kernel
-              const float* qkv_ws = nullptr, int qkv_splits = 0, const float* freqs = nullptr);
+              const float* qkv_ws = nullptr, int qkv_splits = 0, const float* freqs = nullptr,
+              // counters != null: the splits are merged inside the launch by the last-arriving workgroup of each (row, head)
+              // (no attn_combine launch).  M*H ints, zero before the first launch; every launch leaves them zero.
+              int* counters = nullptr);
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
-                                                           int Tc, float scale, FusedQKV fq) {
+                                                           int Tc, float scale, FusedQKV fq, int* __restrict__ counters) {
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
@@ -692,12 +692,47 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
       DT<T>::st(out + ((size_t)m * H + h) * HD + d, A / L);
     } else {
       float* o = ws + (((size_t)m * H + h) * nsplit + split) * (HD + 2);
-      o[2 + d] = A;
-      if (d == 0) {
-        o[0] = M4;
-        o[1] = L;
+      if (counters == nullptr) {
+        o[2 + d] = A;
+        if (d == 0) {
+          o[0] = M4;
+          o[1] = L;
+        }
+      } else {   // in-launch merge: write-through (sc1) stores, read back with sc1 loads - no cache-wide release / invalidate
+        __hip_atomic_store(o + 2 + d, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 0) {
+          __hip_atomic_store(o, M4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(o + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
+  }
+  if (counters == nullptr || nsplit == 1) return;   // partials are merged by attn_combine_kernel
+  // In-launch merge of the splits (cdna_hip_programming.md §5 "In-launch split-K reduction", write-through form): partials were
+  // stored with sc1 (agent-scope) stores; drain them, one relaxed agent-scope ticket per workgroup; the workgroup that draws the
+  // last ticket reads the row's nsplit partials with sc1 loads and merges them in split order (same arithmetic as
+  // attn_combine_kernel: the result does not depend on which workgroup is last).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* ticket_sm = reinterpret_cast<int*>(&sm[0][0]);
+  if (threadIdx.x == 0)
+    *ticket_sm = __hip_atomic_fetch_add(counters + (size_t)m * H + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket_sm != nsplit - 1) return;
+  if (threadIdx.x == 0) __hip_atomic_store(counters + (size_t)m * H + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d < HD) {
+    const float* base = ws + ((size_t)m * H + h) * nsplit * (HD + 2);
+    auto ldc = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float Mx = -INFINITY;
+    for (int sp = 0; sp < nsplit; ++sp) Mx = fmaxf(Mx, ldc(base + (size_t)sp * (HD + 2)));
+    const float mref = (Mx == -INFINITY) ? 0.f : Mx;
+    float L = 0.f, A = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float e = __expf(ldc(base + (size_t)sp * (HD + 2)) - mref);
+      L += ldc(base + (size_t)sp * (HD + 2) + 1) * e;
+      A += ldc(base + (size_t)sp * (HD + 2) + 2 + d) * e;
+    }
+    DT<T>::st(out + ((size_t)m * H + h) * HD + d, A / L);
   }
 }
 
@@ -722,10 +757,12 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                       const FusedQKV* fq) {
+                       const FusedQKV* fq, int* counters) {
   const int M = Bp * Tq;
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
-  // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679; VLG_ATTN_CAP / VLG_ATTN_U are tuning knobs.
+  // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
+  // saves the combine launch but the kernel itself runs 4.6 us longer inside the decode step (75.6 vs 71.0 us average):
+  // 21.92 vs 21.81 s/step, so the split stays.  VLG_ATTN_CAP / VLG_ATTN_U are tuning knobs.
   static const int cap_knob = getenv("VLG_ATTN_CAP") ? atoi(getenv("VLG_ATTN_CAP")) : 2560;
   int nsplit = cap_knob / (M * H);
   const int by_len = (max_pos + 1 + 63) / 64;
@@ -737,7 +774,7 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
   if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
     if constexpr (VEC % 2 == 0)
       attn_partial_kernel<T, HD, VEC, LPR, true, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                      Tc, scale, *fq);
+                                                                                      Tc, scale, *fq, counters);
   } else {
     if (fq != nullptr) {
       set_error("fused qkv attention needs Tq == 1");
@@ -746,27 +783,27 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
     static const int u_knob = getenv("VLG_ATTN_U") ? atoi(getenv("VLG_ATTN_U")) : 4;
     if (u_knob == 8)
       attn_partial_kernel<T, HD, VEC, LPR, false, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
     else if (u_knob == 2)
       attn_partial_kernel<T, HD, VEC, LPR, false, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
     else
       attn_partial_kernel<T, HD, VEC, LPR, false, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr});
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
-  if (nsplit > 1) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+  if (nsplit > 1 && counters == nullptr) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
   return VLG_OK;
 }
 
 template <typename T>
 int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
               int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-              const float* qkv_ws, int qkv_splits, const float* freqs) {
+              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters) {
   FusedQKV fqv{qkv_ws, qkv_splits, freqs};
   const FusedQKV* fq = qkv_ws ? &fqv : nullptr;
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -784,8 +821,8 @@ int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* s
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*);
-template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels

@@ -112,6 +112,7 @@ class Transformer:
         self.time_attn = False
         self.fuse_gemm = True    # decode: fused skinny GEMMs (norm prologue, residual / RoPE+scatter / SwiGLU epilogues)
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
+        self.attn_inlaunch = False  # split-KV partials merged inside the attention launch (slower on MI355X, see gpt.hip)
         self.fuse_qkv = False    # decode: RoPE + KV append fused into the attention kernel
         self.lanes = 0          # 0 = auto: independent batch lanes on forked graph branches (see csrc/gpt.hip)
 
