@@ -252,6 +252,11 @@ template int conv_forward<bf16>(const ConvDesc&, const bf16*, const bf16*, const
 //   fixed order (LDS, no atomics) and written to part[b][block][g][{sum, sumsq}]; gn_finalize_kernel adds the blocks in block
 //   order.  Results do not depend on scheduling: two runs are bit-identical.
 // ---------------------------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct alignas(sizeof(T) * N) GnVec {
+  T v[N];
+};
+
 template <typename T, int VW>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ part, long long P, int C,
                                                        int pos_per_block) {
@@ -268,10 +273,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   const long long p1 = (p0 + pos_per_block < P) ? p0 + pos_per_block : P;
   if (pl < lanes_p) {
     for (long long p = p0 + pl; p < p1; p += lanes_p) {
-      const T* src = x + ((size_t)b * P + p) * C + cv * VW;
+      const GnVec<T, VW> in = *reinterpret_cast<const GnVec<T, VW>*>(x + ((size_t)b * P + p) * C + cv * VW);
 #pragma unroll
       for (int e = 0; e < VW; ++e) {
-        const float v = DT<T>::ld(src + e);
+        const float v = DT<T>::ld(&in.v[e]);
         s[e] += v;
         q[e] += v * v;
       }
@@ -292,41 +297,76 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// stats[b][g][{sum, sumsq}] = sum over blocks of part[b][block][g][.], in block order (4 interleaved chains, then a fixed tree)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
-  __shared__ double sm[4][64];
+// sums part[b][block][g][{sum, sumsq}] over the blocks in a fixed order (16 interleaved chains, then in chain order) and turns them
+// into the group's (mean, rstd) once, in double, rounded to fp32: mr[b][g] = {mean, 1/sqrt(var + eps)}
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restrict__ part, float2* __restrict__ mr, int nblk, double cnt,
+                                                          double eps) {
+  __shared__ double sm[16][64];
   const int b = blockIdx.x, j = threadIdx.x & 63, c = threadIdx.x >> 6;
   double tot = 0.0;
-  for (int k = c; k < nblk; k += 4) tot += part[((size_t)b * nblk + k) * 64 + j];
+  for (int k = c; k < nblk; k += 16) tot += part[((size_t)b * nblk + k) * 64 + j];
   sm[c][j] = tot;
   __syncthreads();
-  if (c == 0) stats[(size_t)b * 64 + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+  if (threadIdx.x < 32) {
+    const int g = threadIdx.x;
+    double su = 0.0, sq = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      su += sm[k][2 * g];
+      sq += sm[k][2 * g + 1];
+    }
+    const double mean = su / cnt;
+    double var = sq / cnt - mean * mean;
+    var = var < 0 ? 0 : var;
+    mr[(size_t)b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + eps)));
+  }
 }
 
+// thread -> fixed VW-channel vector (scale/shift folded once: y = x * a + b with a = rstd * gamma, b = beta - mean * a... kept as
+// the reference's (x - mean) * rstd * gamma + beta so results match the oracle bit for bit), sweeps the block's positions with
+// four vector loads in flight.
 template <typename T, int VW>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const double* __restrict__ stats, long long P,
-                                                       int C, float eps, int do_swish) {
+                                                       const float* __restrict__ beta, const float2* __restrict__ mr, long long P,
+                                                       int C, int do_swish, int pos_per_block) {
   const int b = blockIdx.y;
-  const long long nvec = P * (C / VW);
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nvec) return;
-  const int cv = (int)(i % (C / VW));
+  const int nvec = C / VW;
+  const int lanes_p = 256 / nvec;
+  const int cv = threadIdx.x % nvec, pl = threadIdx.x / nvec;
   const int cg = C / 32;
-  const double cnt = (double)P * cg;
-  const T* src = x + (size_t)b * P * C + i * VW;
-  T* dst = y + (size_t)b * P * C + i * VW;
+  float mean[VW], rstd[VW], ga[VW], be[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) {
     const int c = cv * VW + e;
-    const int g = c / cg;
-    const double mean = stats[((size_t)b * 32 + g) * 2] / cnt;
-    double var = stats[((size_t)b * 32 + g) * 2 + 1] / cnt - mean * mean;
-    var = var < 0 ? 0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float v = (DT<T>::ld(src + e) - (float)mean) * rstd * gamma[c] + beta[c];
-    if (do_swish) v = swish_f(v);
-    DT<T>::st(dst + e, v);
+    const float2 st = mr[(size_t)b * 32 + c / cg];
+    mean[e] = st.x;
+    rstd[e] = st.y;
+    ga[e] = gamma[c];
+    be[e] = beta[c];
+  }
+  const long long p0 = (long long)blockIdx.x * pos_per_block;
+  const long long p1 = (p0 + pos_per_block < P) ? p0 + pos_per_block : P;
+  const size_t base = (size_t)b * P * C + (size_t)cv * VW;
+  constexpr int UN = 4;
+  for (long long p = p0 + pl; p < p1; p += (long long)UN * lanes_p) {
+    GnVec<T, VW> in[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long pp = p + (long long)u * lanes_p;
+      in[u] = *reinterpret_cast<const GnVec<T, VW>*>(x + base + (size_t)(pp < p1 ? pp : p) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long pp = p + (long long)u * lanes_p;
+      if (pp >= p1) break;
+      GnVec<T, VW> o;
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        float v = (DT<T>::ld(&in[u].v[e]) - mean[e]) * rstd[e] * ga[e] + be[e];
+        if (do_swish) v = swish_f(v);
+        DT<T>::st(&o.v[e], v);
+      }
+      *reinterpret_cast<GnVec<T, VW>*>(y + base + (size_t)pp * C) = o;
+    }
   }
 }
 
@@ -342,17 +382,18 @@ int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* 
   const int ppb = kGnPosPerBlock;
   const int nblk = (int)cdiv64(P, ppb);
   dim3 g1((unsigned)nblk, B);
-  double* part = stats + (size_t)B * 64;   // scratch layout: [B][64] finals, then [B][nblk][64] per-block partials
+  double* part = stats + (size_t)B * 64;   // scratch layout: [B][32] float2 (mean, rstd) in the first B*64 doubles' space, then
+                                           // [B][nblk][64] per-block partials
+  float2* mr = reinterpret_cast<float2*>(stats);
+  const double cnt = (double)P * (C / 32);
   if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
     gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
-    gn_finalize_kernel<<<B, 256, 0, st>>>(part, stats, nblk);
-    dim3 g2((unsigned)cdiv64(P * (C / 8), 256), B);
-    gn_apply_kernel<T, 8><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
+    gn_finalize_kernel<<<B, 1024, 0, st>>>(part, mr, nblk, cnt, (double)eps);
+    gn_apply_kernel<T, 8><<<g1, 256, 0, st>>>(x, y, gamma, beta, mr, P, C, swish ? 1 : 0, ppb);
   } else if (C <= 256 && 256 % C == 0) {
     gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
-    gn_finalize_kernel<<<B, 256, 0, st>>>(part, stats, nblk);
-    dim3 g2((unsigned)cdiv64(P * C, 256), B);
-    gn_apply_kernel<T, 1><<<g2, 256, 0, st>>>(x, y, gamma, beta, stats, P, C, eps, swish ? 1 : 0);
+    gn_finalize_kernel<<<B, 1024, 0, st>>>(part, mr, nblk, cnt, (double)eps);
+    gn_apply_kernel<T, 1><<<g1, 256, 0, st>>>(x, y, gamma, beta, mr, P, C, swish ? 1 : 0, ppb);
   } else {
     set_error("group_norm: unsupported channel count %d", C);
     return VLG_ERR_UNSUPPORTED;

@@ -740,6 +740,44 @@ template <typename T, int HD>
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int nsplit) {
   const size_t mh = blockIdx.x;
   const float* base = ws + mh * nsplit * (HD + 2);
+  constexpr int NS = 8, ND = (HD + 63) / 64;
+  if (nsplit <= NS) {
+    // every partial this thread needs is requested before the first use: one memory round trip instead of three
+    float mv[NS], lv[NS], av[NS][ND];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float* b = base + (size_t)(s < nsplit ? s : 0) * (HD + 2);
+      mv[s] = b[0];
+      lv[s] = b[1];
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const int d = threadIdx.x + 64 * k;
+        av[s][k] = b[2 + (d < HD ? d : 0)];
+      }
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < nsplit) M = fmaxf(M, mv[s]);
+    const float mref = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, A[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) A[k] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < nsplit) {
+        const float e = __expf(mv[s] - mref);
+        L += lv[s] * e;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) A[k] += av[s][k] * e;
+      }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const int d = threadIdx.x + 64 * k;
+      if (d < HD) DT<T>::st(out + mh * HD + d, A[k] / L);
+    }
+    return;
+  }
   float M = -INFINITY;
   for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(size_t)s * (HD + 2)]);
   const float mref = (M == -INFINITY) ? 0.f : M;
