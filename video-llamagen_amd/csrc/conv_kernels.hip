@@ -186,6 +186,233 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// halo-tile convolution for the 3x3 (x kt) stride-1 causal convs with Cout % 128 == 0 - every heavy layer of both decoders.
+//
+// conv_mfma_kernel re-fetches each input element once per tap (27x for 3x3x3) through L2 -> LDS: 64 FLOP per staged byte, and
+// the ablation shows the staging path, not the MFMAs, bounds it.  Here a workgroup owns a 2 x 8 x 16 block of
+// output positions (256 rows of the GEMM) x 128 output channels, stages the input patch it needs - (2 + kt - 1) x 10 x 18
+// positions x 32 channels, <= 45 KB - into LDS ONCE per 32-channel chunk and walks the taps over it: the A fragment of tap
+// (a,i,j) is the same LDS image read at a row offset.  Per chunk: 45 KB of input + taps x 8 KB of weights for taps x 2.1 MFLOP
+// (212 FLOP per staged byte at 27 taps).  Weights: one kernel row (3 taps) per step, register prefetch two steps ahead, LDS
+// double buffer: 24 MFMAs per wave between barriers.  Padding (zero in
+// H/W, replicate-first-frame in T) and the nearest-2x upsample are resolved when the patch is gathered.
+// 512 threads = 8 waves (4 along positions x 2 along channels), each a 64 x 64 sub-tile of 32x32x16 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HT_TW = 16, HT_HW = HT_TW + 2;
+constexpr int HT_MAXROWS = (2 + 2) * (8 + 2) * HT_HW;          // 720 patch positions at kt = 3, tile 2 x 8 x 16 (1 x 18 x 18 = 324 for images)
+constexpr int HT_SLOTS = (HT_MAXROWS * 4 + 511) / 512;         // 16-byte chunks per thread per patch: 6
+constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) * sizeof(uint4);   // 2 patches + 2 x 3 weight taps
+
+template <int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 16 columns = 256 positions (2 x 8 for video, 1 x 16 for images)
+__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* __restrict__ in, const bf16* __restrict__ w,
+                                                        const float* __restrict__ bias, const bf16* __restrict__ residual,
+                                                        bf16* __restrict__ out_cl, float* __restrict__ out_planar) {
+  static_assert(HT_TT * HT_TH * HT_TW == 256, "256 positions per tile");
+  constexpr int HT_HH = HT_TH + 2;
+  constexpr int TSH = (HT_TH == 8) ? 7 : 8;   // log2(HT_TH * 16)
+  extern __shared__ __attribute__((aligned(16))) uint4 ht_smem[];
+  auto halo = [&](int buf) { return ht_smem + buf * (HT_MAXROWS * 4); };
+  auto wts = [&](int buf) { return ht_smem + 2 * HT_MAXROWS * 4 + buf * (3 * 128 * 4); };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.y * 128;
+  const int taps = d.kt * 9;
+  const int ncc = d.Cin / 32;
+
+  // tile origin
+  const int nTw = (d.Wo + HT_TW - 1) / HT_TW, nTh = (d.Ho + HT_TH - 1) / HT_TH, nTt = (d.To + HT_TT - 1) / HT_TT;
+  int bid = blockIdx.x;
+  const int x0 = (bid % nTw) * HT_TW;
+  bid /= nTw;
+  const int y0 = (bid % nTh) * HT_TH;
+  bid /= nTh;
+  const int t0 = (bid % nTt) * HT_TT;
+  const int b = bid / nTt;
+
+  // patch gather roles: chunk e = tid + 512 k  ->  patch row e >> 2, 16-byte chunk e & 3
+  const int HF = HT_TT + d.kt - 1;
+  const int nrows = HF * HT_HH * HT_HW;
+  const int He = d.Hi << d.up, We = d.Wi << d.up;
+  const uint4* in16 = reinterpret_cast<const uint4*>(in);
+  long long hoff[HT_SLOTS];   // source chunk index (16-byte units) at channel chunk 0, -1 = zero padding, -2 = no such slot
+  int hslot[HT_SLOTS];
+#pragma unroll
+  for (int k = 0; k < HT_SLOTS; ++k) {
+    const int e = tid + 512 * k;
+    const int hr = e >> 2, ch = e & 3;
+    hoff[k] = -2;
+    hslot[k] = 0;
+    if (hr < nrows) {
+      const int f = hr / (HT_HH * HT_HW), rem = hr - f * (HT_HH * HT_HW);
+      const int y = rem / HT_HW, x = rem - y * HT_HW;
+      int ti = t0 + f - (d.kt - 1);
+      ti = ti < 0 ? 0 : ti;                       // causal: frame 0 replicated in front (conv.py:126-129)
+      ti = ti > d.Ti - 1 ? d.Ti - 1 : ti;         // frames past the end feed only rows that are never written
+      const int uy = y0 + y - 1, ux = x0 + x - 1;
+      hslot[k] = hr * 4 + (ch ^ ((hr >> 2) & 3));
+      hoff[k] = -1;
+      if (uy >= 0 && ux >= 0 && uy < He && ux < We)
+        hoff[k] = (((((long long)b * d.Ti + ti) * d.Hi + (uy >> d.up)) * d.Wi + (ux >> d.up)) * d.Cin) / 8 + ch;
+    }
+  }
+  uint4 hreg[HT_SLOTS];
+  auto halo_gload = [&](int cc) __attribute__((always_inline)) {
+    // unconditional loads (padding slots read chunk 0 of the tensor and are zeroed afterwards): a branch around a load makes
+    // hipcc drain the whole queue (vmcnt(0)) right behind it
+#pragma unroll
+    for (int k = 0; k < HT_SLOTS; ++k) hreg[k] = in16[(hoff[k] >= 0 ? hoff[k] : 0) + cc * 4];
+#pragma unroll
+    for (int k = 0; k < HT_SLOTS; ++k)
+      if (hoff[k] < 0) hreg[k] = make_uint4(0, 0, 0, 0);
+  };
+  auto halo_lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < HT_SLOTS; ++k)
+      if (hoff[k] != -2) halo(buf)[hslot[k]] = hreg[k];
+  };
+
+  // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
+  // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
+  const int wrow = tid >> 2, wch = tid & 3;
+  const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / 8 + wch;
+  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));
+  const int cin8 = d.Cin / 8;
+  const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
+  const int Q = ncc * rows_per_chunk;
+  int l_row = 0, l_cc = 0;   // load iterator: two steps ahead of the MFMAs
+  uint4 wrA0, wrA1, wrA2, wrB0, wrB1, wrB2;   // two register sets as scalars (hipcc leaves uint4 arrays swapped between roles in scratch)
+  wrA0 = wrA1 = wrA2 = wrB0 = wrB1 = wrB2 = make_uint4(0, 0, 0, 0);
+#define w_gload(wr)                                                                   \
+  do {                                                                                \
+    wr##0 = wbase[(size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];                         \
+    wr##1 = wbase[(size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];                         \
+    wr##2 = wbase[(size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];                         \
+    if (++l_row == rows_per_chunk) {                                                  \
+      l_row = 0;                                                                      \
+      if (++l_cc == ncc) l_cc = 0; /* past the end: reload a valid tile, unused */    \
+    }                                                                                 \
+  } while (0)
+#define w_lstore(wr, buf)                      \
+  do {                                         \
+    uint4* wb_ = wts(buf);                     \
+    wb_[0 * 512 + wslot] = wr##0;              \
+    wb_[1 * 512 + wslot] = wr##1;              \
+    wb_[2 * 512 + wslot] = wr##2;              \
+  } while (0)
+
+  // fragment roles
+  int hb[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = wave_m * 64 + mi * 32 + r32;
+    hb[mi] = ((m >> TSH) * HT_HH + ((m >> 4) & (HT_TH - 1))) * HT_HW + (m & 15);
+  }
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  auto compute = [&](const uint4* hbuf, const uint4* wbuf, int toff) __attribute__((always_inline)) {   // toff: patch row offset of tap (a, i, 0)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t af[2], bfr[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = hb[mi] + toff + j;
+          af[mi] = __builtin_bit_cast(bf16x8_t, hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int row = wave_n * 64 + ni * 32 + r32;
+          bfr[ni] = __builtin_bit_cast(bf16x8_t, wbuf[j * 512 + row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  // prologue: patch of chunk 0, weights of steps 0 and 1
+  halo_gload(0);
+  w_gload(wrA);
+  w_gload(wrB);
+  halo_lstore(0);
+  w_lstore(wrA, 0);
+  __syncthreads();
+
+  int row = 0, cc = 0;   // compute iterator: row = a * 3 + i
+  // MINE held step q's weights; they went to LDS during step q - 1, so the set is free for step q + 2.  (A macro, not a lambda
+  // taking the sets by reference: hipcc keeps reference-passed register arrays in scratch.)
+#define VLG_HALO_STEP(q, MINE, NEXT)                                                        \
+  do {                                                                                      \
+    if (row == 0 && cc + 1 < ncc) halo_gload(cc + 1);                                       \
+    w_gload(MINE); /* unconditional: a branch here makes every later wait a vmcnt(0) */     \
+    compute(halo(cc & 1), wts((q) & 1), ((row / 3) * HT_HH + (row % 3)) * HT_HW);           \
+    if (row == 1 && cc + 1 < ncc) halo_lstore((cc + 1) & 1);                                \
+    if ((q) + 1 < Q) w_lstore(NEXT, ((q) + 1) & 1);                                         \
+    __syncthreads();                                                                        \
+    if (++row == rows_per_chunk) {                                                          \
+      row = 0;                                                                              \
+      ++cc;                                                                                 \
+    }                                                                                       \
+  } while (0)
+  for (int q = 0; q < Q; q += 2) {
+    VLG_HALO_STEP(q, wrA, wrB);
+    if (q + 1 < Q) VLG_HALO_STEP(q + 1, wrB, wrA);
+  }
+#undef VLG_HALO_STEP
+#undef w_gload
+#undef w_lstore
+
+  // epilogue: + bias (+ residual) -> channels-last bf16 or planar fp32
+  const long long pper = (long long)d.To * d.Ho * d.Wo;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int co = n0 + wave_n * 64 + ni * 32 + r32;
+      const float bv = bias ? bias[co] : 0.f;
+      long long pe[16];
+      float rv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = wave_m * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int t = t0 + (m >> TSH), y = y0 + ((m >> 4) & (HT_TH - 1)), x = x0 + (m & 15);
+        pe[e] = (t < d.To && y < d.Ho && x < d.Wo) ? (((long long)b * d.To + t) * d.Ho + y) * d.Wo + x : -1;
+      }
+      if (residual) {   // all 16 residual values requested before the first use
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = bf16_to_f32(residual[(pe[e] >= 0 ? pe[e] : 0) * d.Cout + co].v);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (pe[e] < 0) continue;
+        float v = acc[mi][ni][e] + bv;
+        if (residual) v += rv[e];
+        if (out_cl)
+          out_cl[pe[e] * d.Cout + co].v = f32_to_bf16(v);
+        else
+          out_planar[((pe[e] / pper) * d.Cout + co) * pper + (pe[e] % pper)] = v;
+      }
+    }
+  }
+}
+
+static bool conv_halo_ok(const ConvDesc& d) {
+  return d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 && d.ph0 < 0 && d.pw0 < 0 && d.Cin % 32 == 0 &&
+         d.Cout % 128 == 0 && d.To == d.Ti && d.Ho == (d.Hi << d.up) && d.Wo == (d.Wi << d.up);
+}
+
 // direct convolution for layers the MFMA kernel does not tile (Cin % 32 != 0: z_channels / codebook_embed_dim inputs)
 // and for the fp32 handle dtype (parity tests at toy sizes).  One thread per (position, cout).
 template <typename T>
@@ -228,6 +455,32 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
   }
   const long long ptot = (long long)d.B * d.To * d.Ho * d.Wo;
   if constexpr (sizeof(T) == 2) {
+    static const bool halo_off = getenv("VLG_CONV_HALO") != nullptr && atoi(getenv("VLG_CONV_HALO")) == 0;   // A/B knob
+    if (!halo_off && conv_halo_ok(d)) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)HT_LDS_BYTES);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)HT_LDS_BYTES);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
+          return VLG_ERR_HIP;
+        }
+        attr_set = true;
+      }
+      if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 18 x 18 <= HT_MAXROWS)
+        const long long tiles = (long long)d.B * cdiv(d.Ho, 16) * cdiv(d.Wo, HT_TW);
+        conv_halo_kernel<1, 16><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
+                                                                                                           out_planar);
+      } else {
+        const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
+        conv_halo_kernel<2, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
+                                                                                                          out_planar);
+      }
+      return VLG_OK;
+    }
     if (d.Cin % 32 == 0) {
       const bool wide = (d.Cout % 128 == 0);
       const int bn = wide ? 128 : 32;
