@@ -234,3 +234,22 @@ def test_decoders_are_run_to_run_deterministic():
     z = torch.randn(1, 8, 2, 16, 16, generator=g).cuda()
     b = vae.decode(z)
     assert torch.equal(b, vae.decode(z)) and torch.isfinite(b.float()).all()
+
+
+def test_vae_from_pretrained_dir(tmp_path):
+    """modeling_videobase.py:42-53 + modeling_causalvae.py:578-601: config.json + *.ckpt directory, EMA weights with a "module."
+    prefix preferred over "state_dict"; the model built from the directory decodes exactly like one loaded directly."""
+    import json
+    import video_llamagen_amd as V
+    cfg = cases.TINY_VAE
+    sd = {k: torch.from_numpy(v) for k, v in detweights.vae_weights(cfg).items()}
+    d = tmp_path / "vae_dir"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"_class_name": "CausalVAEModel", "hidden_size": cfg["hidden_size"], "z_channels": cfg["z_channels"],
+                                               "embed_dim": cfg["embed_dim"], "hidden_size_mult": list(cfg["hidden_size_mult"]),
+                                               "num_res_blocks": cfg["num_res_blocks"]}))
+    wrong = {k: torch.zeros_like(v) for k, v in sd.items()}
+    torch.save({"ema_state_dict": {"module." + k: v for k, v in sd.items()}, "state_dict": wrong}, str(d / "last.ckpt"))
+    m = V.CausalVAEModel.from_pretrained(str(d), device="cuda", dtype=torch.float32)
+    z = torch.from_numpy(cases.rng(31).standard_normal((1, cfg["embed_dim"], 3, 4, 4), dtype=np.float32))
+    assert torch.equal(m.decode(z), _vae(torch.float32).decode(z))

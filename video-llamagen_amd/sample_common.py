@@ -7,7 +7,7 @@ import torch
 
 
 def unwrap_checkpoint(ckpt):
-    """sample_t2i.py:62-69: DDP "model" / DeepSpeed "module" / "state_dict" / raw FSDP dict."""
+    """sample_t2i.py:62-69: DDP "model" / DeepSpeed "module" / "state_dict" / raw FSDP dict (video_llamagen_amd.io has the strict form)."""
     for k in ("model", "module", "state_dict"):
         if isinstance(ckpt, dict) and k in ckpt:
             return ckpt[k]

@@ -45,6 +45,12 @@ def main(args):
     if is_rank0():
         np.save(args.out + ".npy", videos.cpu().numpy())
         print("videos %s saved to %s.npy" % (tuple(videos.shape), args.out))
+        try:                                                  # first clip as a playable file (mp4 with OpenCV, else gif)
+            from PIL import Image
+            ims = [Image.fromarray(f) for f in videos[0].cpu().numpy()]
+            ims[0].save(args.out + "_0.gif", save_all=True, append_images=ims[1:], duration=500, loop=0)
+        except ImportError:
+            pass
 
 
 if __name__ == "__main__":

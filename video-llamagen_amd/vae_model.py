@@ -59,6 +59,23 @@ class CausalVAEModel:
     def from_config(cls, cfg: dict):
         return cls(**cfg)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        """modeling_videobase.py:42-53: directory with config.json + *.ckpt (the last one in glob order is loaded)."""
+        from . import io as vio
+        cfg, ckpt = vio.find_vae_checkpoint(pretrained_model_name_or_path)
+        model = cls.from_config(cfg)
+        if "device" in kwargs or "dtype" in kwargs:
+            model.to(kwargs.get("device"), kwargs.get("dtype"))
+        model.init_from_ckpt(ckpt)
+        return model
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        """modeling_causalvae.py:578-601 (EMA weights preferred, strict load of the tensors this engine uses)."""
+        from . import io as vio
+        sd = vio.select_vae_state_dict(torch.load(path, map_location="cpu"), ignore_keys)
+        self.load_state_dict(sd, strict=True)
+
     def enable_tiling(self, use_tiling: bool = True):
         self.use_tiling = use_tiling
 
