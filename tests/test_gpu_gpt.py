@@ -380,6 +380,11 @@ def test_diffloss_head_vs_reference_golden(golden):
         latb = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=1.0, noise=torch.from_numpy(noise))
         assert np.abs(to_np(latb) - refb).max() < 1e-3 * max(1.0, np.abs(refb).max()), (graph, lanes)
     m.use_graph, m.lanes = True, 0
+    # the unfused sampler (27 launches per reverse step) stays as the fallback for shapes the fused GEMM does not tile
+    m.fuse_gemm = False
+    latu = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=1.0, noise=torch.from_numpy(noise))
+    assert np.abs(to_np(latu) - refb).max() < 1e-3 * max(1.0, np.abs(refb).max())
+    m.fuse_gemm = True
     a = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=11)      # Philox N(0,1) draws
     b = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=11)
     d = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=12)

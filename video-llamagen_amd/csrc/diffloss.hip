@@ -25,6 +25,27 @@ int dl_make_y(const T* temb, const T* cemb, T* ys, int B, int W, hipStream_t st)
 template int dl_make_y<float>(const float*, const float*, float*, int, int, hipStream_t);
 template int dl_make_y<bf16>(const bf16*, const bf16*, bf16*, int, int, hipStream_t);
 
+// all respaced steps at once: ys[(i*B + b)][w] = rt(silu(rt(temb[i][w] + cemb[b][w]))) - the adaLN inputs do not depend on x, so the
+// modulation GEMM of a token runs once over S*B rows instead of S times over B rows
+template <typename T>
+__global__ __launch_bounds__(256) void dl_make_y_all_kernel(const T* __restrict__ temb, const T* __restrict__ cemb, T* __restrict__ ys, int S, int B,
+                                                            int W) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)S * B * W) return;
+  const int w = (int)(i % W);
+  const int b = (int)((i / W) % B);
+  const int st = (int)(i / ((long long)W * B));
+  const float y = DT<T>::rt(DT<T>::ld(temb + (size_t)st * W + w) + DT<T>::ld(cemb + (size_t)b * W + w));
+  DT<T>::st(ys + i, silu_d(y));
+}
+template <typename T>
+int dl_make_y_all(const T* temb, const T* cemb, T* ys, int S, int B, int W, hipStream_t st) {
+  dl_make_y_all_kernel<T><<<(unsigned)cdiv64((long long)S * B * W, 256), 256, 0, st>>>(temb, cemb, ys, S, B, W);
+  return VLG_OK;
+}
+template int dl_make_y_all<float>(const float*, const float*, float*, int, int, int, hipStream_t);
+template int dl_make_y_all<bf16>(const bf16*, const bf16*, bf16*, int, int, int, hipStream_t);
+
 // g[b] = rt(rt(LayerNorm(h[b]) (* lnw + lnb)) * (1 + scale[b]) + shift[b]);  one workgroup per row, eps 1e-6
 template <typename T>
 __global__ __launch_bounds__(256) void dl_ln_modulate_kernel(const T* __restrict__ h, const T* __restrict__ lnw, const T* __restrict__ lnb,
@@ -150,6 +171,64 @@ int dl_ddpm_step(T* x, const T* out, const float* noise, const StepState* state,
 }
 template int dl_ddpm_step<float>(float*, const float*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int, float, uint64_t, hipStream_t);
 template int dl_ddpm_step<bf16>(bf16*, const bf16*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int, float, uint64_t, hipStream_t);
+
+// One launch per reverse step: x_out = (k < 0 ? x_T : p_sample(x_in, net_out)), then the next network evaluation's input
+// projection hc[b][w] = rt(bias[w] + sum_c x_out[b][c] * Wip[w][c]) (diffloss.py:226, K = C <= 16).  One workgroup per row.
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void dl_step_proj_kernel(const T* __restrict__ x_in, T* __restrict__ x_out, const T* __restrict__ out,
+                                                           const float* __restrict__ noise, const StepState* __restrict__ state, DdpmCoef cf, int k,
+                                                           int S, int B, int C, int b_off, int B_total, float temperature, uint64_t seed,
+                                                           const T* __restrict__ wip, const T* __restrict__ bip, T* __restrict__ hc, int W) {
+  __shared__ float xs[CMAX];
+  const int b = blockIdx.x, c = threadIdx.x, step = state->step;
+  if (c < C) {   // one thread per latent channel draws / steps; the row's values are shared through LDS
+    float r;
+    if (k < 0) {
+      r = noise ? noise[(((size_t)step * (S + 1)) * B_total + b_off + b) * C + c]
+                : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + b), (uint32_t)step, 0u);
+    } else {
+      const float eps = DT<T>::ld(out + (size_t)b * 2 * C + c), v = DT<T>::ld(out + (size_t)b * 2 * C + C + c);
+      const float xv = DT<T>::ld(x_in + (size_t)b * C + c);
+      const float frac = (v + 1.0f) / 2.0f;
+      const float logvar = frac * cf.max_log + (1.0f - frac) * cf.min_log;
+      const float x0 = cf.sqrt_recip * xv - cf.sqrt_recipm1 * eps;
+      const float mean = cf.coef1 * x0 + cf.coef2 * xv;
+      r = mean;
+      if (cf.nonzero) {
+        const float n = noise ? noise[(((size_t)step * (S + 1) + 1 + k) * B_total + b_off + b) * C + c]
+                              : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + b), (uint32_t)step, (uint32_t)(1 + k));
+        r = mean + expf(0.5f * logvar) * n * temperature;
+      }
+    }
+    r = DT<T>::rt(r);
+    xs[c] = r;
+    DT<T>::st(x_out + (size_t)b * C + c, r);
+  }
+  if (hc == nullptr) return;
+  __syncthreads();
+  for (int w = threadIdx.x; w < W; w += 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc)
+      if (cc < C) acc = fmaf(xs[cc], DT<T>::ld(wip + (size_t)w * C + cc), acc);
+    DT<T>::st(hc + (size_t)b * W + w, acc + DT<T>::ld(bip + w));
+  }
+}
+template <typename T>
+int dl_step_proj(const T* x_in, T* x_out, const T* out, const float* noise, const StepState* state, const DdpmCoef& cf, int k, int S, int B, int C,
+                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st) {
+  if (C > 16) {
+    set_error("dl_step_proj: vae_embed_dim %d > 16", C);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  dl_step_proj_kernel<T, 16><<<B, 256, 0, st>>>(x_in, x_out, out, noise, state, cf, k, S, B, C, b_off, B_total, temperature, seed,
+                                                               wip, bip, hc, W);
+  return VLG_OK;
+}
+template int dl_step_proj<float>(const float*, float*, const float*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int,
+                                 float, uint64_t, const float*, const float*, float*, int, hipStream_t);
+template int dl_step_proj<bf16>(const bf16*, bf16*, const bf16*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int, float,
+                                uint64_t, const bf16*, const bf16*, bf16*, int, hipStream_t);
 
 // sampled latent T [B,C] -> cur [B,C] fp32 (next step's input), out_lat[b][step], trace
 template <typename T>

@@ -11,6 +11,7 @@
 //                        q buffer / KV cache at position p                                    (gpt.py:215-227,182-183)
 //             EPI_SWIGLU n-tile taken from both halves of [w1; w3]: g = rt(rt(silu(rt(a))) * rt(b))   (gpt.py:167)
 //             EPI_STORE  out = rt(act(rt(acc + bias))) (T and/or fp32)                        (heads, adapters)
+//             EPI_GATED  h[row][col] = rt(h + rt(gate[row][col] * rt(acc + bias)))           (DiffLoss ResBlock, diffloss.py:128)
 #include "gpt_kernels.h"
 
 #ifdef VLG_KTRACE   // tools/microbench: in-kernel timestamps (100 MHz), thread 0 of every workgroup
@@ -159,18 +160,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   // norm prologue then runs on the activations while the weights are still in flight, and the epilogue never waits on memory.
   const int et = threadIdx.x, ee = et >> 6, el = et & 63;
   const int ecol = n0 + (el & 15);
-  float eres[MT], ecx[MT], ecy[MT];
+  float eres[MT], ecx[MT], ecy[MT];   // ecx doubles as the gate value for EPI_GATED
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
   int epos = 0;
   if constexpr (EPI == EPI_QKV) epos = fa.state->pos;   // scalar load
   auto epilogue_operands = [&]() {
-    if constexpr (EPI == EPI_RESID) {
+    if constexpr (EPI == EPI_RESID || EPI == EPI_GATED) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
         row = row < M ? row : M - 1;
         eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + (size_t)row * N + ecol);
+        if constexpr (EPI == EPI_GATED) ecx[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.gate) + (size_t)row * fa.gate_stride + ecol);
       }
     }
     if constexpr (EPI == EPI_QKV) {
@@ -367,6 +369,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     if (row >= M) continue;
     if constexpr (EPI == EPI_RESID) {
       DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(s0));
+    } else if constexpr (EPI == EPI_GATED) {
+      float v = s0;
+      if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(ecx[mt] * DT<T>::rt(v)));
     } else if constexpr (EPI == EPI_SWIGLU) {
       const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
       DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, DT<T>::rt(silu_g(av)) * bv);
@@ -402,12 +408,176 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   VLG_KT(3);
 }
 
+// ---- LayerNorm + modulate prologue, store epilogue: 16 rows x 16 columns per workgroup, 4 waves, <= 2 K blocks per wave ----------
+template <typename T>
+__device__ __forceinline__ float frag_sum(const u32x4_t& v) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (sizeof(T) == 2)
+      s += lo16(v[j]) + hi16(v[j]);
+    else
+      s += __uint_as_float(v[j]);
+  }
+  return s;
+}
+template <typename T>
+__device__ __forceinline__ float frag_sqdev(const u32x4_t& v, float mu) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (sizeof(T) == 2) {
+      const float a = lo16(v[j]) - mu, b = hi16(v[j]) - mu;
+      s += a * a + b * b;
+    } else {
+      const float a = __uint_as_float(v[j]) - mu;
+      s += a * a;
+    }
+  }
+  return s;
+}
+// v <- rt(rt(((v - mu) * rs) [* gw + gb]) * (1 + sc) + sh), element order as dl_ln_modulate_kernel
+template <typename T>
+__device__ __forceinline__ void ln_frag(u32x4_t& v, float mu, float rs, bool affine, const u32x4_t& gw, const u32x4_t& gb, const u32x4_t& sc,
+                                        const u32x4_t& sh) {
+  auto one = [&](float x, float w_, float b_, float c_, float h_) {
+    float n = (x - mu) * rs;
+    if (affine) n = n * w_ + b_;
+    n = DT<T>::rt(n);
+    return n * (1.0f + c_) + h_;
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (sizeof(T) == 2)
+      v[j] = pack2(one(lo16(v[j]), lo16(gw[j]), lo16(gb[j]), lo16(sc[j]), lo16(sh[j])),
+                   one(hi16(v[j]), hi16(gw[j]), hi16(gb[j]), hi16(sc[j]), hi16(sh[j])));
+    else
+      v[j] = __float_as_uint(one(__uint_as_float(v[j]), __uint_as_float(gw[j]), __uint_as_float(gb[j]), __uint_as_float(sc[j]),
+                                 __uint_as_float(sh[j])));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_ln_kernel(const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, LnGemm fa) {
+  constexpr int KBLK = KB<T>::KBLK, NW = 4, NB = 2;
+  constexpr int EPV = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y == 2 && (gridDim.x & 7) == 0) {   // row halves of one n-tile on one XCD (see gemm_fused_kernel)
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    bx = (id & 7) + 8 * (id >> 4);
+    by = (id >> 3) & 1;
+  }
+  const int n0 = bx * 16, m0 = by * 16;
+  const int nkb = K / KBLK;
+  const bool affine = fa.ln_w != nullptr;
+
+  __shared__ float red[NW][256];
+  __shared__ float stat[2][NW][16];
+  __shared__ u32x4_t gsm[2][256];   // ln weight / bias, K * sizeof(T) <= 4 KiB each
+
+  int row = m0 + r;
+  row = row < M ? row : M - 1;
+  const T* xrow = x + (size_t)row * K;
+  const T* shrow = reinterpret_cast<const T*>(fa.shift) + (size_t)row * fa.mod_stride;
+  const T* scrow = reinterpret_cast<const T*>(fa.scale) + (size_t)row * fa.mod_stride;
+  const T* wrow = w + (size_t)(n0 + r) * K;
+
+  // request order = arrival order: activations, modulation rows, LN affine, weight stream, bias
+  u32x4_t a[NB][1][4], sh[NB][4], sc[NB][4], b[NB][4];
+  u32x4_t gw = u32x4_t{0u, 0u, 0u, 0u}, gb = gw;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int kb = wave + i * NW;
+    if (kb < nkb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) a[i][0][s2] = (reinterpret_cast<const u32x4_t*>(xrow + (size_t)kb * KBLK) + q)[s2 * 4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) sc[i][s2] = (reinterpret_cast<const u32x4_t*>(scrow + (size_t)kb * KBLK) + q)[s2 * 4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) sh[i][s2] = (reinterpret_cast<const u32x4_t*>(shrow + (size_t)kb * KBLK) + q)[s2 * 4];
+    }
+  }
+  const int gi = (int)threadIdx.x < K / EPV ? (int)threadIdx.x : 0;
+  if (affine) {
+    gw = reinterpret_cast<const u32x4_t*>(fa.ln_w)[gi];
+    gb = reinterpret_cast<const u32x4_t*>(fa.ln_b)[gi];
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int kb = wave + i * NW;
+    if (kb < nkb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) b[i][s2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow + (size_t)kb * KBLK) + q + s2 * 4);
+    }
+  }
+  const int t = threadIdx.x, e = t >> 6, l2 = t & 63;
+  const int col = n0 + (l2 & 15);
+  const float bv = fa.bias ? DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col) : 0.f;
+
+  // LayerNorm statistics, two passes as the reference kernel (mean, then the mean of squared deviations)
+  float p = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (wave + i * NW < nkb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) p += frag_sum<T>(a[i][0][s2]);
+    }
+  p += __shfl_xor(p, 16);
+  p += __shfl_xor(p, 32);
+  if (q == 0) stat[0][wave][r] = p;
+  if ((int)threadIdx.x < K / EPV) {
+    gsm[0][threadIdx.x] = gw;
+    gsm[1][threadIdx.x] = gb;
+  }
+  __syncthreads();
+  const float mu = (stat[0][0][r] + stat[0][1][r] + stat[0][2][r] + stat[0][3][r]) / (float)K;
+  float d2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (wave + i * NW < nkb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) d2 += frag_sqdev<T>(a[i][0][s2], mu);
+    }
+  d2 += __shfl_xor(d2, 16);
+  d2 += __shfl_xor(d2, 32);
+  if (q == 0) stat[1][wave][r] = d2;
+  __syncthreads();
+  const float rs = 1.0f / sqrtf((stat[1][0][r] + stat[1][1][r] + stat[1][2][r] + stat[1][3][r]) / (float)K + fa.eps);
+
+  f32x4_t acc[1] = {f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int kb = wave + i * NW;
+    if (kb < nkb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int gidx = kb * (KBLK / EPV) + s2 * 4 + q;
+        ln_frag<T>(a[i][0][s2], mu, rs, affine, gsm[0][gidx], gsm[1][gidx], sc[i][s2], sh[i][s2]);
+      }
+      mfma_blk<T, 1>(a[i], b[i], acc);
+    }
+  }
+#pragma unroll
+  for (int ee = 0; ee < 4; ++ee) red[wave][ee * 64 + lane] = acc[0][ee];
+  __syncthreads();
+  const int orow = m0 + (l2 >> 4) * 4 + e;
+  if (orow >= M) return;
+  float v = red[0][t] + red[1][t] + red[2][t] + red[3][t] + bv;
+  v = DT<T>::rt(v);
+  if (fa.act == ACT_GELU_TANH) v = DT<T>::rt(gelu_g(v));
+  if (fa.act == ACT_SILU) v = DT<T>::rt(silu_g(v));
+  DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)orow * N + col, v);
+}
+
 template <typename T, int MT, int NW, bool PRO>
 void launch_epi(int epi, dim3 grid, hipStream_t st, const T* x, const T* w, int M, int N, int K, const FusedGemm& fa) {
   switch (epi) {
     case EPI_RESID: gemm_fused_kernel<T, MT, NW, PRO, EPI_RESID><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
     case EPI_QKV: gemm_fused_kernel<T, MT, NW, PRO, EPI_QKV><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
     case EPI_SWIGLU: gemm_fused_kernel<T, MT, NW, PRO, EPI_SWIGLU><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
+    case EPI_GATED: gemm_fused_kernel<T, MT, NW, PRO, EPI_GATED><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
     default: gemm_fused_kernel<T, MT, NW, PRO, EPI_STORE><<<grid, 64 * NW, 0, st>>>(x, w, M, N, K, fa); break;
   }
 }
@@ -440,7 +610,8 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
   const int nkb_all = K / KB<T>::KBLK;
   // few n-tiles (N = D: wo, w2): 16-row workgroups, so twice the CUs stream and each pulls half the activations through its
   // vector-memory pipe (the row halves of a tile share an XCD, see the kernel); 8 waves when K needs more than 16 K-block slots
-  const bool rows16 = !pro && epi == EPI_RESID && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0 && !(fa.slabs && fa.counters);
+  const bool rows16 = !pro && (epi == EPI_RESID || epi == EPI_GATED || epi == EPI_STORE) && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0 &&
+                      !(fa.slabs && fa.counters);
   if (rows16) mt = 1;
   const bool wide = (mt * nh >= 4) || (rows16 && nkb_all > 16);   // 8 waves so one pass of the K loop covers the whole K range
   int splits = 1;
@@ -480,6 +651,26 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
 #undef VLG_GF
   return VLG_OK;
 }
+template <typename T>
+bool gemm_ln_fused_ok(int M, int N, int K) {
+  constexpr int KBLK = KB<T>::KBLK;
+  return M >= 1 && N % 16 == 0 && K % KBLK == 0 && K / KBLK <= 8 && (size_t)K * sizeof(T) <= 4096;
+}
+template bool gemm_ln_fused_ok<float>(int, int, int);
+template bool gemm_ln_fused_ok<bf16>(int, int, int);
+
+template <typename T>
+int gemm_ln_fused(const T* x, const T* w, int M, int N, int K, const LnGemm& fa, hipStream_t st) {
+  if (!gemm_ln_fused_ok<T>(M, N, K)) {
+    set_error("gemm_ln_fused: shape M=%d N=%d K=%d not covered", M, N, K);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  gemm_ln_kernel<T><<<dim3(N / 16, cdiv(M, 16)), 256, 0, st>>>(x, w, M, N, K, fa);
+  return VLG_OK;
+}
+template int gemm_ln_fused<float>(const float*, const float*, int, int, int, const LnGemm&, hipStream_t);
+template int gemm_ln_fused<bf16>(const bf16*, const bf16*, int, int, int, const LnGemm&, hipStream_t);
+
 template int gemm_fused<float>(const float*, const float*, int, int, int, bool, int, const FusedGemm&, hipStream_t);
 template int gemm_fused<bf16>(const bf16*, const bf16*, int, int, int, bool, int, const FusedGemm&, hipStream_t);
 

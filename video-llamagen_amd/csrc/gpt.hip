@@ -14,13 +14,14 @@
 #include <cmath>
 #include <memory>
 
+#include "conv_kernels.h"
 #include "gpt_kernels.h"
 
 using namespace vlg;
 
 struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
-  DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x;   // DiffLoss head
+  DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
   DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
@@ -48,6 +49,7 @@ struct vlg_gpt {
   std::vector<DdpmCoef> dcoef;       // per respaced step
   std::vector<float> dsincos;        // [S][256] timestep embedding inputs
   DevBuf dtemb;                      // [S][W] time_embed(t) table, handle dtype
+  DevBuf dadaln_bias;                // fp32 copy of diffloss.adaln_all.bias (bias operand of the batched modulation GEMM)
   bool dtemb_ready = false;
 
   // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
@@ -563,6 +565,7 @@ struct Runner {
   // DiffLoss.sample (diffloss.py:35-52): x_T ~ N(0,1); S reverse steps of {SimpleMLPAdaLN(x, t, c = z) -> p_sample}.
   // z = hl [B, D] (normed hidden of the last position).  All S steps are enqueued (and graph-captured) back to back.
   int diffloss_head(const T* z, const vlg_sampling_params& sp, const float* noise, float* out_lat, float* trace) {
+    if (diffloss_fused_ok()) return diffloss_head_fused(z, sp, noise, out_lat, trace);
     const int Wd = h->dW, C = h->C, dd = h->dDepth, S = h->dS, MR = (3 * dd + 2) * Wd;
     const std::string p = "diffloss.net.";
     T* cemb = ln->d_cemb.as<T>();
@@ -596,6 +599,100 @@ struct Runner {
     return dl_finish<T>(x, ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * C, trace, state(), B, C, N, b0, Btot, st);
   }
 
+  // The same sampler with 8-12 instead of 27 launches per reverse step (800-1200 vs 2700 per token; the head is launch-latency bound):
+  //  * the adaLN modulation vectors depend on (t, z) only, not on x: one [S*B, W] x [W, (3d+2)W] GEMM per token up front;
+  //  * p_sample + the next evaluation's input projection (K = C) in one elementwise launch;
+  //  * mlp.0 (+bias, SiLU) and final_layer.linear as single fused-GEMM launches; mlp.2 with bias, gate and residual in its
+  //    epilogue (EPI_GATED); LayerNorm + modulate as the prologue of mlp.0 / final_layer.linear (gemm_ln_kernel) when W fits.
+  bool diffloss_fused_ok() {
+    const int Wd = h->dW, C = h->C;
+    return h->fuse_gemm && C <= 16 && (2 * C) % 16 == 0 && gemm_fused_ok<T>(B, Wd, Wd, false, EPI_STORE) &&
+           gemm_fused_ok<T>(B, Wd, Wd, false, EPI_GATED) && gemm_fused_ok<T>(B, 2 * C, Wd, false, EPI_STORE);
+  }
+  int diffloss_head_fused(const T* z, const vlg_sampling_params& sp, const float* noise, float* out_lat, float* trace) {
+    const int Wd = h->dW, C = h->C, dd = h->dDepth, S = h->dS, MR = (3 * dd + 2) * Wd;
+    const std::string p = "diffloss.net.";
+    T* cemb = ln->d_cemb.as<T>();
+    T* ys = ln->d_ys.as<T>();
+    T* mod_all = ln->d_mod.as<T>();
+    T* hc = ln->d_h.as<T>();
+    T* g = ln->d_g.as<T>();
+    T* g1 = ln->d_g1.as<T>();
+    T* dout = ln->d_out.as<T>();
+    T* xa = ln->d_x.as<T>();
+    T* xb = ln->d_x2.as<T>();
+    if (z) VLG_TRY(linear_b(z, p + "cond_embed", cemb, B, Wd, h->D, ACT_NONE));
+    VLG_TRY(dl_make_y_all<T>(h->dtemb.as<T>(), cemb, ys, S, B, Wd, st));
+    {   // [S*B, W] x [W, MR]: a real GEMM (74 GFLOP at S 100, B 32, W 1024) - the 128 x 128 MFMA tile kernel of the decoders, as a 1x1 conv
+      ConvDesc cd;
+      cd.B = 1; cd.Ti = cd.To = 1; cd.Hi = cd.Ho = 1; cd.Wi = cd.Wo = S * B; cd.Cin = Wd; cd.Cout = MR;
+      cd.kt = cd.kh = cd.kw = 1; cd.up = 0;
+      VLG_TRY(conv_forward<T>(cd, ys, W<T>("diffloss.adaln_all.weight"), h->dadaln_bias.as<float>(), nullptr, mod_all, nullptr, st));
+    }
+    const T* wip = W<T>(p + "input_proj.weight");
+    const T* bip = W<T>(p + "input_proj.bias");
+    // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
+    const bool ln_in_gemm = gemm_ln_fused_ok<T>(B, Wd, Wd) && gemm_ln_fused_ok<T>(B, 2 * C, Wd) && !getenv("VLG_DIFFLOSS_NO_LN_FUSE");
+    DdpmCoef none{};
+    VLG_TRY(dl_step_proj<T>(xb, xa, nullptr, noise, state(), none, -1, S, B, C, b0, Btot, sp.temperature, sp.seed, wip, bip, hc, Wd, st));
+    for (int k = 0; k < S; ++k) {
+      const int i = S - 1 - k;
+      const T* mod = mod_all + (size_t)i * B * MR;
+      for (int blk = 0; blk < dd; ++blk) {
+        const std::string q = p + "res_blocks." + std::to_string(blk) + ".";
+        const T* m0 = mod + (size_t)blk * 3 * Wd;   // [shift | scale | gate] (diffloss.py:125)
+        if (ln_in_gemm) {
+          LnGemm f0;
+          f0.ln_w = W<T>(q + "in_ln.weight");
+          f0.ln_b = W<T>(q + "in_ln.bias");
+          f0.shift = m0;
+          f0.scale = m0 + Wd;
+          f0.mod_stride = MR;
+          f0.out = g1;
+          f0.bias = W<T>(q + "mlp.0.bias");
+          f0.act = ACT_SILU;
+          VLG_TRY(gemm_ln_fused<T>(hc, W<T>(q + "mlp.0.weight"), B, Wd, Wd, f0, st));
+        } else {
+          VLG_TRY(dl_ln_modulate<T>(hc, W<T>(q + "in_ln.weight"), W<T>(q + "in_ln.bias"), m0, m0 + Wd, MR, g, B, Wd, st));
+          FusedGemm f0;
+          f0.out = g1;
+          f0.bias = W<T>(q + "mlp.0.bias");
+          f0.act = ACT_SILU;
+          VLG_TRY(gemm_fused<T>(g, W<T>(q + "mlp.0.weight"), B, Wd, Wd, false, EPI_STORE, f0, st));
+        }
+        FusedGemm f2;
+        f2.h = hc;
+        f2.bias = W<T>(q + "mlp.2.bias");
+        f2.gate = m0 + 2 * Wd;
+        f2.gate_stride = MR;
+        VLG_TRY(gemm_fused<T>(g1, W<T>(q + "mlp.2.weight"), B, Wd, Wd, false, EPI_GATED, f2, st));
+      }
+      const T* mf = mod + (size_t)dd * 3 * Wd;      // [shift | scale] (diffloss.py:145)
+      if (ln_in_gemm) {
+        LnGemm ff;
+        ff.shift = mf;
+        ff.scale = mf + Wd;
+        ff.mod_stride = MR;
+        ff.out = dout;
+        ff.bias = W<T>(p + "final_layer.linear.bias");
+        VLG_TRY(gemm_ln_fused<T>(hc, W<T>(p + "final_layer.linear.weight"), B, 2 * C, Wd, ff, st));
+      } else {
+        VLG_TRY(dl_ln_modulate<T>(hc, nullptr, nullptr, mf, mf + Wd, MR, g, B, Wd, st));
+        FusedGemm ff;
+        ff.out = dout;
+        ff.bias = W<T>(p + "final_layer.linear.bias");
+        VLG_TRY(gemm_fused<T>(g, W<T>(p + "final_layer.linear.weight"), B, 2 * C, Wd, false, EPI_STORE, ff, st));
+      }
+      // x_{k+1} from x_k (ping-pong) and, unless this was the last step, the next evaluation's input projection
+      T* xin = (k & 1) ? xb : xa;
+      T* xout = (k & 1) ? xa : xb;
+      VLG_TRY(dl_step_proj<T>(xin, xout, dout, noise, state(), h->dcoef[i], k, S, B, C, b0, Btot, sp.temperature, sp.seed, wip, bip,
+                              k + 1 < S ? hc : nullptr, Wd, st));
+    }
+    const T* xfin = (S & 1) ? xb : xa;
+    return dl_finish<T>(xfin, ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * C, trace, state(), B, C, N, b0, Btot, st);
+  }
+
   // time_embed(t) for every respaced step: [S,256] sincos -> Linear -> SiLU -> Linear (diffloss.py:93-96), once per handle
   int build_time_table() {
     const int Wd = h->dW, S = h->dS;
@@ -607,6 +704,9 @@ struct Runner {
     VLG_TRY(linear_b(sc.as<T>(), "diffloss.net.time_embed.mlp.0", t1.as<T>(), S, Wd, 256, ACT_SILU));
     VLG_TRY(linear_b(t1.as<T>(), "diffloss.net.time_embed.mlp.2", h->dtemb.as<T>(), S, Wd, Wd, ACT_NONE));
     VLG_HIP(hipStreamSynchronize(st));
+    const int MR = (3 * h->dDepth + 2) * Wd;
+    VLG_TRY(h->dadaln_bias.reserve((size_t)MR * sizeof(float)));
+    VLG_TRY(upload_convert(h->dadaln_bias.p, VLG_F32, W<T>("diffloss.adaln_all.bias"), DT<T>::code, 1, MR, st));
     h->dtemb_ready = true;
     return VLG_OK;
   }
@@ -681,8 +781,9 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
     need(h->dS, Wd, 256);
     need(h->dS, Wd, Wd);
     VLG_TRY(ln.d_cemb.reserve((size_t)Bp * Wd * e));
-    VLG_TRY(ln.d_ys.reserve((size_t)Bp * Wd * e));
-    VLG_TRY(ln.d_mod.reserve((size_t)Bp * MR * e));
+    VLG_TRY(ln.d_ys.reserve((size_t)h->dS * Bp * Wd * e));
+    VLG_TRY(ln.d_mod.reserve((size_t)h->dS * Bp * MR * e));
+    VLG_TRY(ln.d_x2.reserve((size_t)Bp * h->C * e));
     VLG_TRY(ln.d_h.reserve((size_t)Bp * Wd * e));
     VLG_TRY(ln.d_g.reserve((size_t)Bp * Wd * e));
     VLG_TRY(ln.d_g1.reserve((size_t)Bp * Wd * e));

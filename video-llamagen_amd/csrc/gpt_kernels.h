@@ -23,11 +23,13 @@ bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_
 size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 
 // ---- fused skinny GEMM (gemm_fused.hip): prologue RMSNorm + epilogue residual / RoPE+scatter / SwiGLU / store -------------
-enum FusedEpi { EPI_RESID = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_STORE = 3 };
+enum FusedEpi { EPI_RESID = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_STORE = 3, EPI_GATED = 4 };
 struct FusedGemm {
   const void* norm_w = nullptr;   // PRO: RMSNorm weight [K] (dtype T)
   float eps = 1e-5f;
-  void* h = nullptr;              // EPI_RESID: residual stream [M,N], updated in place
+  void* h = nullptr;              // EPI_RESID / EPI_GATED: residual stream [M,N], updated in place
+  const void* gate = nullptr;     // EPI_GATED: h = rt(h + rt(gate[m*gate_stride + n] * rt(acc + bias)))   (diffloss.py:128)
+  int gate_stride = 0;
   void* qbuf = nullptr;           // EPI_QKV: q [M,H,hd]; caches [Bp,H,S,hd]
   void* kc = nullptr;
   void* vc = nullptr;
@@ -51,6 +53,25 @@ template <typename T>
 bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
 template <typename T>
 int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st);
+
+// LayerNorm + adaLN-modulate prologue (DiffLoss ResBlock / FinalLayer, diffloss.py:55-56,120-128,141-148) fused into the skinny GEMM:
+//   out = rt(act(rt(bias + W . rt(rt(LN(x) [* ln_w + ln_b]) * (1 + scale[row]) + shift[row]))))
+// shift / scale: [M] rows of stride mod_stride; ln_w / ln_b null for elementwise_affine = False.
+struct LnGemm {
+  const void* ln_w = nullptr;
+  const void* ln_b = nullptr;
+  const void* shift = nullptr;
+  const void* scale = nullptr;
+  int mod_stride = 0;
+  float eps = 1e-6f;
+  void* out = nullptr;
+  const void* bias = nullptr;
+  int act = 0;
+};
+template <typename T>
+bool gemm_ln_fused_ok(int M, int N, int K);
+template <typename T>
+int gemm_ln_fused(const T* x, const T* w, int M, int N, int K, const LnGemm& fa, hipStream_t st);
 
 // out[m][n] = rt(act(rt(sum_s slab[s][m][n])));  out_f32 (optional) receives float(rt(sum)) (gpt.py:371)
 // bias (optional, dtype T, [N]) is added to the fp32 sum before the first rounding (nn.Linear with bias)
@@ -113,6 +134,13 @@ struct DdpmCoef {   // one respaced reverse step (gaussian_diffusion.py:232-252,
 };
 template <typename T>
 int dl_make_y(const T* temb, const T* cemb, T* ys, int B, int W, hipStream_t st);
+// the same for all S respaced steps: ys [S*B, W], row i*B + b
+template <typename T>
+int dl_make_y_all(const T* temb, const T* cemb, T* ys, int S, int B, int W, hipStream_t st);
+// x_out = x_T (k < 0) or p_sample(x_in, out) (k >= 0); hc = input_proj(x_out) when hc != null.  x_in != x_out.
+template <typename T>
+int dl_step_proj(const T* x_in, T* x_out, const T* out, const float* noise, const StepState* state, const DdpmCoef& cf, int k, int S, int B, int C,
+                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st);
 template <typename T>
 int dl_ln_modulate(const T* h, const T* lnw, const T* lnb, const T* shift, const T* scale, int mod_stride, T* g, int B, int W, hipStream_t st);
 template <typename T>
