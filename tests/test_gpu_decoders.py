@@ -253,3 +253,17 @@ def test_vae_from_pretrained_dir(tmp_path):
     m = V.CausalVAEModel.from_pretrained(str(d), device="cuda", dtype=torch.float32)
     z = torch.from_numpy(cases.rng(31).standard_normal((1, cfg["embed_dim"], 3, 4, 4), dtype=np.float32))
     assert torch.equal(m.decode(z), _vae(torch.float32).decode(z))
+
+
+def test_vae_full_size_batch_invariance():
+    """BASELINE config-4 decoder shape (constructor defaults, embed_dim 8, latent 5x32x32 -> 17x256x256), random weights: videos are
+    independent, so decoding two at once equals decoding them one by one bit for bit (every conv tile, GroupNorm statistic and
+    attention row is per-sample), the output is finite and has the Q13 frame count."""
+    import video_llamagen_amd as V
+    vae = V.VAE_models["VAE-16"](embed_dim=8).to("cuda", torch.bfloat16).eval()
+    vae.init_random_weights(seed=3)
+    z = torch.randn(2, 8, 5, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    both = vae.decode(z)
+    assert tuple(both.shape) == (2, 3, 17, 256, 256) and torch.isfinite(both.float()).all()
+    assert torch.equal(both[0:1], vae.decode(z[0:1])) and torch.equal(both[1:2], vae.decode(z[1:2]))
+    assert not torch.equal(both[0], both[1])
