@@ -214,6 +214,91 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64-row x 64-column tile for M > 32 (prefill: M = B' x 120 rows; decode at B' = 64; widths the fused decode GEMM does not
+// cover, GPT-3B).  gemm_mfma_kernel gives every 16-column workgroup its own copy of the activation rows: at 64 rows that is
+// 4 bytes of activations per byte of weights through each CU's vector-memory pipe (GPT-3B decode streamed weights at 1.7 TB/s).
+// Here the workgroup's 4 waves own 16 columns each and SHARE the 64 x KBLK activation tile through LDS (double buffer,
+// register-staged, 16-byte-chunk XOR swizzle); each wave streams only its own weight rows (non-temporal): 1 : 1.
+// Output: fp32 slabs like gemm_mfma_kernel (gridDim.z K-slices), consumed by the reduce_* kernels.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x, const T* __restrict__ w, float* __restrict__ slabs, int M,
+                                                        int N, int K) {
+  constexpr int KBLK = GemmT<T>::KBLK;   // 256 bytes per row per K block for both dtypes
+  __shared__ u32x4_t As[2][64 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16, m0 = blockIdx.y * 64;
+  const int split = blockIdx.z, splits = gridDim.z;
+  const int nkb = K / KBLK;
+
+  // activation loader: 1024 chunks per tile, 4 per thread
+  const u32x4_t* asrc[4];
+  int aslot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c >> 4, ch = c & 15;
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    asrc[i] = reinterpret_cast<const u32x4_t*>(x + (size_t)gr * K) + ch;
+    aslot[i] = row * 16 + (ch ^ (row & 15));
+  }
+  const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(w + (size_t)(n0 + r) * K) + q;
+  constexpr int CPB = KBLK * (int)sizeof(T) / 16;   // 16-byte chunks per row per K block = 16
+
+  f32x4_t acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t ra[4], b[4], bn[4];
+  int kb = split;
+  if (kb < nkb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kb * CPB];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) b[s2] = __builtin_nontemporal_load(wsrc + (size_t)kb * CPB + s2 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) As[0][aslot[i]] = ra[i];
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; kb < nkb; kb += splits) {
+    const int kn = kb + splits;
+    const bool more = kn < nkb;
+    const int kl = more ? kn : kb;   // unconditional loads (the last iteration re-reads its own block): counted waits stay exact
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kl * CPB];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) bn[s2] = __builtin_nontemporal_load(wsrc + (size_t)kl * CPB + s2 * 4);
+    u32x4_t af[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = mt * 16 + r;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) af[mt][s2] = As[buf][row * 16 + ((s2 * 4 + q) ^ (row & 15))];
+    }
+    mfma_block<T, 4>(af, b, acc);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[buf ^ 1][aslot[i]] = ra[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) b[s2] = bn[s2];
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = m0 + mt * 16 + q * 4 + e;
+      if (row < M) slabs[((size_t)split * M + row) * N + n0 + r] = acc[mt][e];
+    }
+  }
+}
+
 // fallback for shapes the MFMA kernel does not tile (K % KBLK != 0 or N % 16 != 0: adapters with
 // vae_embed_dim = 8, toy widths): one wave per output element, lanes stride over K.
 template <typename T>
@@ -235,13 +320,23 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const T* __restrict__ x
 int gemm_max_splits() { return 8; }
 
 // launch geometry shared by gemm_slabs and the workspace sizing
-static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits) {
+static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits, bool* wide = nullptr) {
   naive = (K % kblk != 0) || (N % 16 != 0);
   mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   mchunks = cdiv(M, mt * 16);
   splits = 1;
+  if (wide) *wide = false;
   if (naive) return;
   const int nkb = K / kblk;
+  static const bool wide_off = getenv("VLG_GEMM_WIDE") != nullptr && atoi(getenv("VLG_GEMM_WIDE")) == 0;   // A/B knob
+  if (M > 32 && N % 64 == 0 && !wide_off) {   // gemm_wide_kernel: 64 x 64 tiles, K slices so that ~3 workgroups per CU stream
+    if (wide) *wide = true;
+    splits = 768 / ((N / 64) * mchunks);
+    if (splits > nkb) splits = nkb;
+    if (splits > gemm_max_splits()) splits = gemm_max_splits();
+    if (splits < 1) splits = 1;
+    return;
+  }
   const int ntiles = N / 16;
   splits = 1024 / (ntiles * mchunks);
   if (splits > nkb / 4) splits = nkb / 4;
@@ -263,13 +358,18 @@ int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* spli
     set_error("gemm: bad shape %d %d %d", M, N, K);
     return VLG_ERR_BAD_SHAPE;
   }
-  bool naive;
+  bool naive, wide;
   int mt, mchunks, splits;
-  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits);
+  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits, &wide);
   if (naive) {
     const long long total = (long long)M * N;
     gemm_naive_kernel<T><<<dim3((unsigned)((total + 3) / 4)), 256, 0, st>>>(x, w, ws, M, N, K);
     *splits_out = 1;
+    return VLG_OK;
+  }
+  if (wide) {
+    gemm_wide_kernel<T><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
+    *splits_out = splits;
     return VLG_OK;
   }
   dim3 grid(N / 16, mchunks, splits);
@@ -289,6 +389,8 @@ template <typename T>
 bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_t st) {
   constexpr int KBLK = GemmT<T>::KBLK;
   if (K % KBLK != 0 || F % 16 != 0) return false;
+  static const bool wide_off = getenv("VLG_GEMM_WIDE") != nullptr && atoi(getenv("VLG_GEMM_WIDE")) == 0;
+  if (M > 32 && F % 32 == 0 && !wide_off) return false;   // 64-row tiles: gemm_wide_kernel + reduce_silu_mul stream the weights faster
   const int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   dim3 grid(F / 16, cdiv(M, mt * 16), 1);
   if (mt == 4)
