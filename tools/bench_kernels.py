@@ -38,6 +38,26 @@ def bench_attn(Bp=32, H=20, S=5240, hd=64):
         print(f"attn Bp={Bp} H={H} hd={hd} pos={pos}: {us:8.1f} us  {by / us / 1e3:8.1f} GB/s (incl. combine + host sync in entry point)")
 
 
+def bench_attn_rotating(Bp=32, H=20, S=5240, hd=64, nbuf=8):
+    """the same launch cycling through `nbuf` distinct KV buffers (as the 36 layers of a decode step do): TLB / page-locality effects"""
+    dt = torch.bfloat16
+    q = torch.randn(Bp, H, hd, device="cuda", dtype=dt)
+    ks = [torch.randn(Bp, H, S, hd, device="cuda", dtype=dt) for _ in range(nbuf)]
+    vs = [torch.randn(Bp, H, S, hd, device="cuda", dtype=dt) for _ in range(nbuf)]
+    out = torch.empty(Bp, H * hd, device="cuda", dtype=dt)
+    st = L.stream_ptr()
+    for pos in (1023, 2679, 5239):
+        it = [0]
+
+        def call():
+            i = it[0] % nbuf
+            it[0] += 1
+            L.check(L.lib().vlg_attn_decode(L.ptr(q), L.ptr(ks[i]), L.ptr(vs[i]), L.ptr(out), Bp, H, S, hd, pos, None, 0, 0, L.VLG_BF16, st))
+        us = timeit(call, iters=4 * nbuf, warm=nbuf)
+        by = 2.0 * Bp * H * hd * (pos + 1) * 2
+        print(f"attn rotating x{nbuf} pos={pos}: {us:8.1f} us  {by / us / 1e3:8.1f} GB/s")
+
+
 def bench_linear(M=32):
     dt = torch.bfloat16
     st = L.stream_ptr()
@@ -53,5 +73,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("attn", "all"):
         bench_attn()
+    if what in ("attn_rot", "all"):
+        bench_attn_rotating()
     if what in ("linear", "all"):
         bench_linear()
