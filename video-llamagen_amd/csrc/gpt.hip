@@ -528,6 +528,9 @@ struct Runner {
       fa.out = ln->t1.as<T>();
       fa.act = ACT_GELU_TANH;
       VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("vae_latent_adapter2.fc1.weight"), Bp, D, D, true, EPI_STORE, fa, st));
+      if (h->C <= 16)   // fc2 (N = C) + CFG combine + stores in one launch (3 before)
+        return latent_out_fc2<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter2.fc2.weight"), ln->cur_lat.as<float>(),
+                                 out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, D, N, sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
       VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter2.fc2.weight", ln->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
       return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
                                    sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
@@ -713,7 +716,13 @@ struct Runner {
 
   int decode_step(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
-    if (h->cfg.model_type == VLG_T2V) {
+    if (h->cfg.model_type == VLG_T2V && h->fuse_gemm && h->C <= 16 && gemm_fused_ok<T>(Bp, D, D, false, EPI_STORE)) {
+      // latent -> adapter.fc1 -> GELU in one launch, fc2 as one fused-GEMM launch (5 launches before)
+      VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
+      FusedGemm f2;
+      f2.out = ln->x.as<T>();
+      VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
+    } else if (h->cfg.model_type == VLG_T2V) {
       VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
       VLG_TRY(linear(ln->latT.as<T>(), "vae_latent_adapter.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
       VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter.fc2.weight", ln->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));

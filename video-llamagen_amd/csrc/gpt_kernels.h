@@ -127,6 +127,13 @@ template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp,
                        int C, int N, float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
 
+// fused forms for the decode step (one workgroup per row; C <= 16): latent_to_rows + adapter.fc1 + GELU, and adapter2.fc2 + finish
+template <typename T>
+int latent_in_fc1(const float* cur, const T* w1, T* t1, int B, int Bp, int C, int D, hipStream_t st);
+template <typename T>
+int latent_out_fc2(const T* t1, const T* w2, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int D, int N,
+                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
+
 // ---- DiffLoss head pieces (diffloss.hip) ---------------------------------------------------------------------
 struct DdpmCoef {   // one respaced reverse step (gaussian_diffusion.py:232-252,288-292,334-339)
   float sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log;

@@ -1073,6 +1073,101 @@ int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, con
 template int latent_head_finish<float>(const float*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
 template int latent_head_finish<bf16>(const bf16*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
 
+// ---- t2v decode step, latent side in two launches instead of six ---------------------------------------------------------
+// latent_in: cur fp32 [B,C] -> (rows duplicated for CFG) -> t1[m][d] = rt(gelu_tanh(rt(sum_c rt(cur[m % B][c]) * W1[d][c])))
+// = latent_to_rows + vae_latent_adapter.fc1 + GELU (gpt_video.py:296-297; K = C <= 16).  One workgroup per row.
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void latent_in_fc1_kernel(const float* __restrict__ cur, const T* __restrict__ w1, T* __restrict__ t1, int B,
+                                                            int C, int D) {
+  __shared__ float xs[CMAX];
+  const int m = blockIdx.x;
+  if ((int)threadIdx.x < C) xs[threadIdx.x] = DT<T>::rt(cur[(size_t)(m % B) * C + threadIdx.x]);
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) acc = fmaf(xs[c], DT<T>::ld(w1 + (size_t)d * C + c), acc);
+    DT<T>::st(t1 + (size_t)m * D + d, gelu_tanh_f(DT<T>::rt(acc)));
+  }
+}
+template <typename T>
+int latent_in_fc1(const float* cur, const T* w1, T* t1, int B, int Bp, int C, int D, hipStream_t st) {
+  if (C > 16) {
+    set_error("latent_in_fc1: vae_embed_dim %d > 16", C);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  latent_in_fc1_kernel<T, 16><<<Bp, 256, 0, st>>>(cur, w1, t1, B, C, D);
+  return VLG_OK;
+}
+template int latent_in_fc1<float>(const float*, const float*, float*, int, int, int, int, hipStream_t);
+template int latent_in_fc1<bf16>(const float*, const bf16*, bf16*, int, int, int, int, hipStream_t);
+
+// latent_out: y[row][c] = rt(sum_k t1[row][k] * W2[c][k]) for the row (and its unconditional partner), then the CFG combine and the
+// stores of latent_head_finish = vae_latent_adapter2.fc2 (N = C <= 16) + finish.  One workgroup per user row.
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void latent_out_fc2_kernel(const T* __restrict__ t1, const T* __restrict__ w2, float* __restrict__ cur,
+                                                             float* __restrict__ out_lat, float* __restrict__ trace,
+                                                             const StepState* __restrict__ state, int B, int Bp, int C, int D, int N,
+                                                             float cfg_scale, int cfg_interval, int b_off, int B_total) {
+  __shared__ float red[4][2][CMAX];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool pair = Bp > B;
+  float ac[CMAX], au[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) ac[c] = au[c] = 0.f;
+  for (int k = threadIdx.x; k < D; k += 256) {
+    const float xc = DT<T>::ld(t1 + (size_t)b * D + k);
+    const float xu = pair ? DT<T>::ld(t1 + (size_t)(b + B) * D + k) : 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+        const float wv = DT<T>::ld(w2 + (size_t)c * D + k);
+        ac[c] = fmaf(xc, wv, ac[c]);
+        au[c] = fmaf(xu, wv, au[c]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    ac[c] = wave_sum(ac[c]);
+    au[c] = wave_sum(au[c]);
+    if (lane == 0) {
+      red[wave][0][c] = ac[c];
+      red[wave][1][c] = au[c];
+    }
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const int step = state->step;
+  float v = DT<T>::rt(red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+  if (pair) {
+    const bool flag = !(cfg_interval > -1 && (step - 1) > cfg_interval);   // generate.py:113-114
+    if (flag) {
+      const float u = DT<T>::rt(red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
+      v = DT<T>::rt(u + (v - u) * cfg_scale);
+    }
+  }
+  cur[(size_t)b * C + c] = v;
+  out_lat[((size_t)b * N + step) * C + c] = v;
+  if (trace) trace[((size_t)step * B_total + b_off + b) * C + c] = v;
+}
+template <typename T>
+int latent_out_fc2(const T* t1, const T* w2, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int D, int N,
+                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total) {
+  if (C > 16) {
+    set_error("latent_out_fc2: vae_embed_dim %d > 16", C);
+    return VLG_ERR_UNSUPPORTED;
+  }
+  latent_out_fc2_kernel<T, 16><<<B, 256, 0, st>>>(t1, w2, cur, out_lat, trace, state, B, Bp, C, D, N, cfg_scale, cfg_interval, b_off,
+                                                  B_total > 0 ? B_total : B);
+  return VLG_OK;
+}
+template int latent_out_fc2<float>(const float*, const float*, float*, float*, float*, const StepState*, int, int, int, int, int, float, int,
+                                   hipStream_t, int, int);
+template int latent_out_fc2<bf16>(const bf16*, const bf16*, float*, float*, float*, const StepState*, int, int, int, int, int, float, int,
+                                  hipStream_t, int, int);
+
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;
   s->step += 1;
