@@ -98,7 +98,11 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
 /* bytes the last generate() call moved algorithmically (weights + KV read/write + logits), for roofline */
 int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* kv_bytes, double* other_bytes);
 /* options: "graph" (default 1) = HIP-graph replay of the decode step; "time_attn" (default 0) = eager decode loop
- * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step   */
+ * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
+ * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
+ * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "fuse_qkv" (0: RoPE + KV append inside attention),
+ * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "lanes" (0 = auto:
+ * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
 /* event-timed attention launches of the last generate() with time_attn=1: total ms, total algorithmic KV bytes
  * (2 * Bp * D * (p+1) * elem per launch), number of launches                                                      */
