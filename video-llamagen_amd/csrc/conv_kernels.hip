@@ -204,10 +204,14 @@ constexpr int HT_MAXROWS = (2 + 2) * (8 + 2) * HT_HW;          // 720 patch posi
 constexpr int HT_SLOTS = (HT_MAXROWS * 4 + 511) / 512;         // 16-byte chunks per thread per patch: 6
 constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) * sizeof(uint4);   // 2 patches + 2 x 3 weight taps
 
-template <int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 16 columns = 256 positions (2 x 8 for video, 1 x 16 for images)
-__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* __restrict__ in, const bf16* __restrict__ w,
-                                                        const float* __restrict__ bias, const bf16* __restrict__ residual,
-                                                        bf16* __restrict__ out_cl, float* __restrict__ out_planar) {
+// T = bf16: 32-channel chunks, v_mfma_f32_32x32x16_bf16.  T = float (the reference runs the VQ-16 decoder in fp32): 16-channel
+// chunks - the same 64-byte patch rows and LDS image - on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak instead of a direct conv).
+template <typename T, int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 16 columns = 256 positions (2 x 8 video, 1 x 16 images)
+__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+                                                        const float* __restrict__ bias, const T* __restrict__ residual,
+                                                        T* __restrict__ out_cl, float* __restrict__ out_planar) {
+  constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int KC = 4 * EPV;                // channels per chunk step: one 64-byte patch row
   static_assert(HT_TT * HT_TH * HT_TW == 256, "256 positions per tile");
   constexpr int HT_HH = HT_TH + 2;
   constexpr int TSH = (HT_TH == 8) ? 7 : 8;   // log2(HT_TH * 16)
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
   const int r32 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.y * 128;
   const int taps = d.kt * 9;
-  const int ncc = d.Cin / 32;
+  const int ncc = d.Cin / KC;
 
   // tile origin
   const int nTw = (d.Wo + HT_TW - 1) / HT_TW, nTh = (d.Ho + HT_TH - 1) / HT_TH, nTt = (d.To + HT_TT - 1) / HT_TT;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
       hslot[k] = hr * 4 + (ch ^ ((hr >> 2) & 3));
       hoff[k] = -1;
       if (uy >= 0 && ux >= 0 && uy < He && ux < We)
-        hoff[k] = (((((long long)b * d.Ti + ti) * d.Hi + (uy >> d.up)) * d.Wi + (ux >> d.up)) * d.Cin) / 8 + ch;
+        hoff[k] = (((((long long)b * d.Ti + ti) * d.Hi + (uy >> d.up)) * d.Wi + (ux >> d.up)) * d.Cin) / EPV + ch;
     }
   }
   uint4 hreg[HT_SLOTS];
@@ -277,9 +281,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
   const int wrow = tid >> 2, wch = tid & 3;
-  const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / 8 + wch;
+  const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
   const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));
-  const int cin8 = d.Cin / 8;
+  const int cin8 = d.Cin / EPV;   // 16-byte chunks per (cout, tap) weight row
   const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
   const int Q = ncc * rows_per_chunk;
   int l_row = 0, l_cc = 0;   // load iterator: two steps ahead of the MFMAs
@@ -323,21 +327,36 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf16x8_t af[2], bfr[2];
+        uint4 af[2], bfr[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = hb[mi] + toff + j;
-          af[mi] = __builtin_bit_cast(bf16x8_t, hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+          af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int row = wave_n * 64 + ni * 32 + r32;
-          bfr[ni] = __builtin_bit_cast(bf16x8_t, wbuf[j * 512 + row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+          bfr[ni] = wbuf[j * 512 + row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
         }
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]),
+                                                                    acc[mi][ni], 0, 0, 0);
+        } else {
+          // K = 2 per MFMA: element e of the hh = 0 lanes' chunk pairs with element e of the hh = 1 lanes' chunk - any pairing of
+          // the 16 channels works as long as both operands use the same one
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&af[mi].x)[e]), __uint_as_float((&bfr[ni].x)[e]),
+                                                                   acc[mi][ni], 0, 0, 0);
+        }
       }
     }
   };
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
       }
       if (residual) {   // all 16 residual values requested before the first use
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = bf16_to_f32(residual[(pe[e] >= 0 ? pe[e] : 0) * d.Cout + co].v);
+        for (int e = 0; e < 16; ++e) rv[e] = DT<T>::ld(residual + (pe[e] >= 0 ? pe[e] : 0) * d.Cout + co);
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
         float v = acc[mi][ni][e] + bv;
         if (residual) v += rv[e];
         if (out_cl)
-          out_cl[pe[e] * d.Cout + co].v = f32_to_bf16(v);
+          DT<T>::st(out_cl + pe[e] * d.Cout + co, v);
         else
           out_planar[((pe[e] / pper) * d.Cout + co) * pper + (pe[e] % pper)] = v;
       }
@@ -408,8 +427,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const bf16* 
   }
 }
 
-static bool conv_halo_ok(const ConvDesc& d) {
-  return d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 && d.ph0 < 0 && d.pw0 < 0 && d.Cin % 32 == 0 &&
+static bool conv_halo_ok(const ConvDesc& d, int kc) {
+  return d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 && d.ph0 < 0 && d.pw0 < 0 && d.Cin % kc == 0 &&
          d.Cout % 128 == 0 && d.To == d.Ti && d.Ho == (d.Hi << d.up) && d.Wo == (d.Wi << d.up);
 }
 
@@ -454,15 +473,15 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
     return VLG_ERR_BAD_ARG;
   }
   const long long ptot = (long long)d.B * d.To * d.Ho * d.Wo;
-  if constexpr (sizeof(T) == 2) {
+  {
     static const bool halo_off = getenv("VLG_CONV_HALO") != nullptr && atoi(getenv("VLG_CONV_HALO")) == 0;   // A/B knob
-    if (!halo_off && conv_halo_ok(d)) {
-      static bool attr_set = false;
+    if (!halo_off && conv_halo_ok(d, sizeof(T) == 2 ? 32 : 16)) {
+      static bool attr_set = false;   // per instantiation of conv_forward<T>
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)HT_LDS_BYTES);
         if (e == hipSuccess)
-          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)HT_LDS_BYTES);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
@@ -472,15 +491,17 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       }
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 18 x 18 <= HT_MAXROWS)
         const long long tiles = (long long)d.B * cdiv(d.Ho, 16) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<1, 16><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
-                                                                                                           out_planar);
+        conv_halo_kernel<T, 1, 16><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
+                                                                                                              out_planar);
       } else {
         const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<2, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
-                                                                                                          out_planar);
+        conv_halo_kernel<T, 2, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
+                                                                                                             out_planar);
       }
       return VLG_OK;
     }
+  }
+  if constexpr (sizeof(T) == 2) {
     if (d.Cin % 32 == 0) {
       const bool wide = (d.Cout % 128 == 0);
       const int bn = wide ? 128 : 32;
