@@ -444,3 +444,24 @@ def test_full_width_decode_paths_agree():
     m.fuse_gemm = False
     f = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
     assert torch.isfinite(e).all() and (e[:, :3] - f[:, :3]).abs().max().item() < 3e-2 * max(scale, e.abs().max().item())
+
+
+def test_generate_edge_shapes():
+    """Ragged and degenerate shapes against the oracle (fp32, greedy ids bit-exact): one sample, one new token (prefill only), a
+    condition with a single valid text token, a fully valid one, and the last position the RoPE table holds."""
+    import video_llamagen_amd as V
+    cfg = cases.TINY_T2I
+    m, _ = product_gpt(cfg, torch.float32)
+    sd = detweights.gpt_weights(cfg)
+    om = O.GPTOracle(cfg, sd, "fp32")
+    T, N = cfg["cls_token_num"], cfg["block_size"]
+    for B, lens, n_new, cfg_scale in ((1, [1], 1, 1.0), (1, [T], N, 1.0), (2, [1, T], 5, 2.0), (3, [2, 64, 119], 1, 3.0)):
+        c, mk = cases.text_cond(B, T, cfg["caption_dim"], lens=lens)
+        ids = V.generate(m, torch.from_numpy(c), n_new, torch.from_numpy(mk), cfg_scale=cfg_scale, sample_logits=False)
+        ref = O.generate(om, c, n_new, mk, cfg_scale=cfg_scale, sample_logits=False)
+        assert tuple(ids.shape) == (B, n_new) and (ids.cpu().numpy() == ref).all(), (B, lens, n_new, cfg_scale)
+    mc, _ = product_gpt(cases.TINY_C2I, torch.float32)
+    omc = O.GPTOracle(cases.TINY_C2I, detweights.gpt_weights(cases.TINY_C2I), "fp32")
+    cls = np.array([0, cases.TINY_C2I["num_classes"] - 1], np.int64)           # first and last class id; null class = num_classes
+    ids = V.generate(mc, torch.from_numpy(cls), 1, cfg_scale=1.5, sample_logits=False)
+    assert (ids.cpu().numpy() == O.generate(omc, cls, 1, cfg_scale=1.5, sample_logits=False)).all()
