@@ -134,15 +134,17 @@ def load_videovq_classes():
 
 
 def load_vae_tiling_methods():
-    """CausalVAEModel's tiled_decode / tiled_decode2d / blend_v / blend_h as plain functions (the class itself needs diffusers)."""
+    """CausalVAEModel's tiled_decode / tiled_decode2d / tiled_encode / tiled_encode2d / blend_v / blend_h as plain functions (the class
+    itself needs diffusers).  tiled_encode returns the moments tensor (DiagonalGaussianDistribution is replaced by the identity)."""
     import torch
     path = os.path.join(REF, "CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py")
     tree = ast.parse(open(path).read())
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CausalVAEModel"][0]
-    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("tiled_decode", "tiled_decode2d", "blend_v", "blend_h")]
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("tiled_decode", "tiled_decode2d", "tiled_encode", "tiled_encode2d",
+                                                                                 "blend_v", "blend_h")]
     stub = ast.ClassDef(name="TilingStub", bases=[], keywords=[], body=keep, decorator_list=[])
     mod = ast.Module(body=[stub], type_ignores=[])
     ast.fix_missing_locations(mod)
-    ns = dict(torch=torch)
+    ns = dict(torch=torch, DiagonalGaussianDistribution=lambda moments: moments)
     exec(compile(mod, path, "exec"), ns)
     return ns["TilingStub"]

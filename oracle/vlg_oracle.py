@@ -843,6 +843,13 @@ def vae_tiled_decode(decode_fn, x, tile_latent_min_size, tile_latent_min_size_t,
     return np.concatenate(outs, axis=2)
 
 
+def vae_tiled_encode(moments_fn, x, tile_sample_min_size, tile_sample_min_size_t, tile_latent_min_size, overlap_factor=0.125):
+    """CausalVAEModel.tiled_encode / tiled_encode2d (modeling_causalvae.py:444-466,491-530) over a plain `moments_fn(x) -> [B,2C,t,h,w]`:
+    the same chunk / tile / blend / crop scheme as tiled_decode with the roles of the sample and latent tile sizes swapped (tiles and
+    strides are measured in pixels, the blend extent and the crop in latent cells).  Returns the moments."""
+    return vae_tiled_decode(moments_fn, x, tile_sample_min_size, tile_sample_min_size_t, tile_latent_min_size, overlap_factor)
+
+
 # ----------------------------------------------------------------------------
 # tokenizer_video VQ-VAE decode  (tokenizer/tokenizer_video/vqvae.py:48-51,89-125,245-319; attention.py:121-247,496-510)
 # ----------------------------------------------------------------------------

@@ -234,6 +234,12 @@ def gold_vae(out):
     st.tile_sample_min_size, st.tile_latent_min_size, st.tile_latent_min_size_t, st.tile_overlap_factor = 32, 4, 3, 0.25
     zt = cases.rng(35).standard_normal((1, cfg["embed_dim"], 5, 6, 6), dtype=np.float32)
     out["vae_tiled"] = st.tiled_decode(t(zt)).numpy()
+    # tiled encode (modeling_causalvae.py:444-466,491-530): [1,3,9,48,48] tiles in t (chunks of 5 frames, one shared) and in h, w (32-px
+    # tiles at stride 24, 1 latent row/column blended)
+    st.encoder, st.quant_conv = enc, qc
+    st.tile_sample_min_size, st.tile_latent_min_size, st.tile_sample_min_size_t, st.tile_overlap_factor = 32, 4, 5, 0.25
+    xt = cases.rng(37).standard_normal((1, 3, 9, 48, 48), dtype=np.float32)
+    out["vae_tiled_moments"] = st.tiled_encode(t(xt)).numpy()
 
 
 def gold_t2v(out):

@@ -218,6 +218,14 @@ def test_vae_encode(golden, dt):
         np.testing.assert_allclose(zs, O.VAEOracle.posterior_sample(ref, noise.numpy()), atol=5e-3 * np.abs(zs).max())
     y = m.decode(post.mode())                                     # encode -> decode round trip runs end to end
     assert tuple(y.shape) == (1, 3, 9, 32, 32)
+    # tiled_encode vs the reference's own tiling methods (toy tile sizes: 32-px tiles, 5-frame chunks, overlap 0.25)
+    m.enable_tiling()
+    m.tile_sample_min_size, m.tile_latent_min_size, m.tile_sample_min_size_t, m.tile_overlap_factor = 32, 4, 5, 0.25
+    xt = cases.rng(37).standard_normal((1, 3, 9, 48, 48), dtype=np.float32)
+    mt = to_np(m.encode(torch.from_numpy(xt)).parameters)
+    reft = g["vae_tiled_moments"]
+    assert mt.shape == reft.shape == (1, 16, 3, 6, 6)
+    assert np.abs(mt - reft).max() < tol * np.abs(reft).max()
 
 
 def test_decoders_are_run_to_run_deterministic():

@@ -226,3 +226,9 @@ def test_encoders(golden):
     mo = vae.encode_moments(xv)
     assert mo.shape == gv["vae_moments"].shape == (1, 16, 3, 4, 4)
     np.testing.assert_allclose(mo, gv["vae_moments"], atol=2e-3 * np.abs(gv["vae_moments"]).max())
+    # tiled_encode (modeling_causalvae.py:444-466,491-530): [1,3,9,48,48] with 32-px tiles, 5-frame chunks, overlap 0.25
+    xt = cases.rng(37).standard_normal((1, 3, 9, 48, 48), dtype=np.float32)
+    mt = O.vae_tiled_encode(vae.encode_moments, xt, 32, 5, 4, 0.25)
+    ref = gv["vae_tiled_moments"]
+    assert mt.shape == ref.shape == (1, 16, 3, 6, 6)
+    np.testing.assert_allclose(mt, ref, atol=2e-3 * np.abs(ref).max())

@@ -251,7 +251,52 @@ class CausalVAEModel:
             raise L.VlgError(-2, "x must be [B,3,T,H,W], got %s" % (tuple(x.shape),))
         if self.use_tiling and (x.shape[-1] > self.tile_sample_min_size or x.shape[-2] > self.tile_sample_min_size
                                 or x.shape[-3] > self.tile_sample_min_size_t):
-            raise L.VlgError(-3, "tiled_encode is not implemented")
+            return self.tiled_encode(x)
+        return DiagonalGaussianDistribution(self._encode_moments(x))
+
+    @torch.no_grad()
+    def tiled_encode(self, x):
+        """modeling_causalvae.py:444-466: temporal chunks of tile_sample_min_size_t frames sharing one frame (the repeated latent frame
+        of every later chunk is dropped), each chunk tiled spatially by tiled_encode2d."""
+        t = x.shape[2]
+        starts = list(range(0, t, self.tile_sample_min_size_t - 1))
+        if len(starts) == 1:
+            spans = [[0, t]]
+        else:
+            spans = [[starts[i], starts[i + 1] + 1] for i in range(len(starts) - 1)]
+            if spans[-1][1] > t:
+                spans[-1][1] = t
+            elif spans[-1][1] < t:
+                spans.append([starts[-1], t])
+        parts = []
+        for n, (a, b) in enumerate(spans):
+            mom = self.tiled_encode2d(x[:, :, a:b], return_moments=True)
+            parts.append(mom if n == 0 else mom[:, :, 1:])
+        return DiagonalGaussianDistribution(torch.cat(parts, dim=2))
+
+    @torch.no_grad()
+    def tiled_encode2d(self, x, return_moments=False):
+        """modeling_causalvae.py:491-530: tile_sample_min_size-pixel tiles at stride size*(1-overlap), moments of neighbouring tiles
+        blended over tile_latent_min_size*overlap latent cells, each tile cropped to the stride in latent cells."""
+        stride = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
+        extent = int(self.tile_latent_min_size * self.tile_overlap_factor)
+        keep = self.tile_latent_min_size - extent
+        grid = [[self._encode_moments(x[:, :, :, i:i + self.tile_sample_min_size, j:j + self.tile_sample_min_size])
+                 for j in range(0, x.shape[4], stride)] for i in range(0, x.shape[3], stride)]
+        out_rows = []
+        for i, row in enumerate(grid):
+            cells = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self.blend_v(grid[i - 1][j], tile, extent)
+                if j > 0:
+                    tile = self.blend_h(row[j - 1], tile, extent)
+                cells.append(tile[:, :, :, :keep, :keep])
+            out_rows.append(torch.cat(cells, dim=4))
+        moments = torch.cat(out_rows, dim=3)
+        return moments if return_moments else DiagonalGaussianDistribution(moments)
+
+    def _encode_moments(self, x):
         B, _, T, H, W = [int(v) for v in x.shape]
         xf = x.to(device=self._device, dtype=torch.float32).contiguous()
         n = len(self.config.hidden_size_mult) - 1
@@ -261,7 +306,7 @@ class CausalVAEModel:
         mom = torch.empty((B, 2 * self.config.embed_dim, t, H >> n, W >> n), dtype=torch.float32, device=self._device)
         with torch.cuda.device(self._device):
             L.check(L.lib().vlg_vae_encode(self._handle, L.ptr(xf), B, T, H, W, L.ptr(mom), L.stream_ptr(self._device)))
-        return DiagonalGaussianDistribution(mom)
+        return mom
 
     def _decode_plain(self, z):
         B, _, t, hh, ww = [int(s) for s in z.shape]
