@@ -1116,16 +1116,38 @@ __global__ __launch_bounds__(256) void latent_out_fc2_kernel(const T* __restrict
   float ac[CMAX], au[CMAX];
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) ac[c] = au[c] = 0.f;
-  for (int k = threadIdx.x; k < D; k += 256) {
-    const float xc = DT<T>::ld(t1 + (size_t)b * D + k);
-    const float xu = pair ? DT<T>::ld(t1 + (size_t)(b + B) * D + k) : 0.f;
+  constexpr int EPV = 16 / (int)sizeof(T);   // 16-byte vectors: all loads of a thread are issued before the first use
+  if (D % EPV == 0) {
+    for (int kv = threadIdx.x; kv < D / EPV; kv += 256) {
+      const Pack<T, EPV> xc = *reinterpret_cast<const Pack<T, EPV>*>(t1 + (size_t)b * D + kv * EPV);
+      Pack<T, EPV> xu = xc;
+      if (pair) xu = *reinterpret_cast<const Pack<T, EPV>*>(t1 + (size_t)(b + B) * D + kv * EPV);
+      Pack<T, EPV> wv[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) {
-        const float wv = DT<T>::ld(w2 + (size_t)c * D + k);
-        ac[c] = fmaf(xc, wv, ac[c]);
-        au[c] = fmaf(xu, wv, au[c]);
-      }
+      for (int c = 0; c < CMAX; ++c) wv[c] = *reinterpret_cast<const Pack<T, EPV>*>(w2 + (size_t)(c < C ? c : 0) * D + kv * EPV);
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            const float w_ = DT<T>::ld(&wv[c].v[e]);
+            ac[c] = fmaf(DT<T>::ld(&xc.v[e]), w_, ac[c]);
+            au[c] = fmaf(DT<T>::ld(&xu.v[e]), w_, au[c]);
+          }
+        }
+    }
+  } else {
+    for (int k = threadIdx.x; k < D; k += 256) {
+      const float xc = DT<T>::ld(t1 + (size_t)b * D + k);
+      const float xu = pair ? DT<T>::ld(t1 + (size_t)(b + B) * D + k) : 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+          const float wv = DT<T>::ld(w2 + (size_t)c * D + k);
+          ac[c] = fmaf(xc, wv, ac[c]);
+          au[c] = fmaf(xu, wv, au[c]);
+        }
+    }
   }
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
