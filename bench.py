@@ -102,11 +102,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VLG_BENCH_ONE_DEVICE"):      # rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("VLG_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for the one-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import video_llamagen_amd as V
     vae_t = (a.num_frames - 1) // 4 + 1
@@ -136,7 +142,8 @@ def main():
                 frames.append(((v.clamp(-1, 1) + 1) * 127.5).to(torch.uint8))   # custom_to_video, :49-58
             out = torch.cat(frames, 0)
         if world > 1:
-            gathered = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=device)
+            # concatenated form [world * B, ...]: accepted by RCCL and by gloo (the stacked form [world, B, ...] is RCCL-only)
+            gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=device)
             dist.all_gather_into_tensor(gathered, out.contiguous())
             out = gathered
         return out
