@@ -95,6 +95,20 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
                      const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids,
                      float* d_out_lat, float* d_trace, void* stream);
 
+/* Iteration-level batching for the request front-end (class-conditional token models; the role vLLM's model runner plays
+ * in the reference's autoregressive/serve/, model_runner.py:845-886 + sampler.py:46-125).  A session owns `rows` KV-cache slots
+ * of max_new_tokens + 1 positions; with sp->cfg_scale > 1 every slot carries its unconditional partner internally.
+ *   session_step  advances EVERY slot by one token, each slot at its own position.  h_row_class[rows] (host memory):
+ *                 >= 0  start a request with this class id in the slot (its first token is sampled by this step),
+ *                 -1    continue the slot's request,   -2  leave the slot idle.
+ *                 The call returns after the step has run; tokens stay on the device.
+ *   session_read  copies the first n_tokens tokens of a slot to host memory (call it when the request is done, before
+ *                 the slot is reused).                                                                               */
+int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp);
+int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class);
+int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out);
+int vlg_gpt_session_end(vlg_gpt_t* h);
+
 /* bytes the last generate() call moved algorithmically (weights + KV read/write + logits), for roofline */
 int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* kv_bytes, double* other_bytes);
 /* options: "graph" (default 1) = HIP-graph replay of the decode step; "time_attn" (default 0) = eager decode loop

@@ -164,7 +164,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
   int epos = 0;
-  if constexpr (EPI == EPI_QKV) epos = fa.state->pos;   // scalar load
+  const int32_t* erow_pos = nullptr;   // iteration-level batching: per-row positions (StepState::row_pos)
+  if constexpr (EPI == EPI_QKV) {
+    epos = fa.state->pos;   // scalar loads
+    erow_pos = fa.state->row_pos;
+  }
   auto epilogue_operands = [&]() {
     if constexpr (EPI == EPI_RESID || EPI == EPI_GATED) {
 #pragma unroll
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
         row = row < M ? row : M - 1;
-        const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
+        const int pp = (erow_pos ? erow_pos[row / fa.Tq] : epos) + row % fa.Tq;
+        const float* cp = fa.freqs + ((size_t)pp * (fa.hd / 2) + d / 2) * 2;
         ecx[mt] = cp[0];
         ecy[mt] = cp[1];
       }
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       const int sec = col / D, within = col - sec * D;
       const int hh = within / fa.hd, d = within - hh * fa.hd;
       const int bq = row / fa.Tq, tq = row - bq * fa.Tq;
-      const int p = epos + tq;
+      const int p = (erow_pos ? erow_pos[bq] : epos) + tq;
       const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
       float o = xs;
       if (sec < 2) {

@@ -54,6 +54,8 @@ struct vlg_gpt {
 
   // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
   std::vector<std::unique_ptr<Lane>> lanes;
+  struct Session;                    // iteration-level batching (vlg_gpt_session_*)
+  std::unique_ptr<Session> ses;
   int lanes_opt = 0;   // 0 = auto
   int last_lanes = 1;
   hipStream_t s_int = nullptr;   // weight uploads
@@ -739,6 +741,19 @@ struct Runner {
     return advance_state(state(), st);
   }
 
+  // one iteration of the request scheduler: every row at its own position (StepState::row_pos / row_step), inputs per row_cls
+  int session_step(const vlg_sampling_params& sp, const int32_t* row_cls, int32_t* out_ids) {
+    const int D = h->D;
+    VLG_TRY(gather_session_rows<T>(W<T>("cls_embedding.embedding_table.weight"), h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V,
+                                   row_cls, ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, st));
+    if (fused_decode_ok()) {
+      VLG_TRY(layers_fused());
+      return head_fused(sp, nullptr, out_ids, nullptr, nullptr);
+    }
+    VLG_TRY(layers(1, S - 1));
+    return head(ln->xn.as<T>(), sp, nullptr, out_ids, nullptr, nullptr);
+  }
+
   int prefill(const void* d_cond, const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D, Tc = h->Tc;
     VLG_TRY(set_state(state(), 0, 0, st));
@@ -962,6 +977,146 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Iteration-level batching (the request front-end; reference: vLLM's model_runner.execute_model as used by
+// autoregressive/serve/).  A session owns `rows` KV-cache slots of max_new_tokens + 1 positions.  Each step advances EVERY slot by
+// one token, each at its own position: a slot starts a request (class id given: the c2i condition token at position 0),
+// continues one, or idles.  One captured hipGraph per session; positions, token indices and inputs live in device arrays.
+// ---------------------------------------------------------------------------------------------------------------
+struct vlg_gpt::Session {
+  Lane ln;
+  int R = 0, Rp = 0, S = 0, maxN = 0;
+  bool cfg = false;
+  vlg_sampling_params sp{};
+  DevBuf row_pos, row_step, row_cls, out_ids;
+  std::vector<int32_t> pos;           // host mirror: -1 = idle, else input position of the slot's next step
+  std::vector<int32_t> h_pos, h_step, h_cls;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  ~Session() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+};
+
+namespace {
+template <typename T>
+int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& sp) {
+  auto ses = std::make_unique<vlg_gpt::Session>();
+  ses->R = R;
+  ses->cfg = sp.cfg_scale > 1.0f;
+  ses->Rp = ses->cfg ? 2 * R : R;
+  ses->maxN = maxN;
+  ses->S = round_up(h->Tc + maxN, 8);
+  ses->sp = sp;
+  VLG_TRY(reserve_lane(h, ses->ln, R, ses->Rp, ses->S));
+  const size_t nb = (size_t)ses->Rp * sizeof(int32_t);
+  VLG_TRY(ses->row_pos.reserve(nb));
+  VLG_TRY(ses->row_step.reserve(nb));
+  VLG_TRY(ses->row_cls.reserve(nb));
+  VLG_TRY(ses->out_ids.reserve((size_t)R * maxN * sizeof(int32_t)));
+  VLG_HIP(hipMemset(ses->row_pos.p, 0, nb));
+  VLG_HIP(hipMemset(ses->row_step.p, 0, nb));
+  VLG_HIP(hipMemset(ses->ln.cur_tok.p, 0, (size_t)ses->Rp * sizeof(int32_t)));
+  VLG_HIP(hipMemset(ses->out_ids.p, 0, (size_t)R * maxN * sizeof(int32_t)));
+  ses->pos.assign(R, -1);
+  ses->h_pos.assign(ses->Rp, 0);
+  ses->h_step.assign(ses->Rp, 0);
+  ses->h_cls.assign(ses->Rp, h->cfg.num_classes);
+  hipStream_t st = ses->ln.st;
+  VLG_TRY(set_row_state(ses->ln.state.as<StepState>(), ses->row_pos.as<int32_t>(), ses->row_step.as<int32_t>(), st));
+  Runner<T> r{h, &ses->ln, st, R, ses->Rp, maxN, ses->S, 0, R, nullptr};
+  if (h->use_graph) {
+    VLG_HIP(hipStreamSynchronize(st));
+    VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = r.session_step(ses->sp, ses->row_cls.as<int32_t>(), ses->out_ids.as<int32_t>());
+    hipError_t ee = hipStreamEndCapture(st, &ses->graph);
+    VLG_TRY(rc);
+    VLG_HIP(ee);
+    VLG_HIP(hipGraphInstantiate(&ses->exec, ses->graph, nullptr, nullptr, 0));
+  }
+  h->ses = std::move(ses);
+  return VLG_OK;
+}
+
+template <typename T>
+int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
+  vlg_gpt::Session& s = *h->ses;
+  const int R = s.R, null_cls = h->cfg.num_classes;
+  for (int b = 0; b < R; ++b) {
+    const int c = h_row_class[b];
+    int cls = -1;
+    if (c >= 0) {                      // start a request in this slot
+      VLG_CHECK(c <= null_cls, VLG_ERR_BAD_ARG, "class id %d out of range", c);
+      s.pos[b] = 0;
+      cls = c;
+    } else if (c == -1 && s.pos[b] >= 0) {   // continue
+      s.pos[b] += 1;
+      VLG_CHECK(s.pos[b] < s.maxN, VLG_ERR_BAD_SHAPE, "slot %d stepped past max_new_tokens %d", b, s.maxN);
+    } else {                           // idle (or told to stop): park the slot at position 0 on the null class
+      s.pos[b] = -1;
+      cls = null_cls;
+    }
+    const int p = s.pos[b] < 0 ? 0 : s.pos[b];
+    s.h_pos[b] = p;
+    s.h_step[b] = p;                   // c2i: one condition token, so token index == input position
+    s.h_cls[b] = cls;
+    if (s.cfg) {                       // unconditional partner row: same position, null class at the start (generate.py:131)
+      s.h_pos[b + R] = p;
+      s.h_step[b + R] = p;
+      s.h_cls[b + R] = cls >= 0 ? null_cls : -1;
+    }
+  }
+  hipStream_t st = s.ln.st;
+  const size_t nb = (size_t)s.Rp * sizeof(int32_t);
+  VLG_HIP(hipMemcpyAsync(s.row_pos.p, s.h_pos.data(), nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipMemcpyAsync(s.row_step.p, s.h_step.data(), nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipMemcpyAsync(s.row_cls.p, s.h_cls.data(), nb, hipMemcpyHostToDevice, st));
+  if (s.exec) {
+    VLG_HIP(hipGraphLaunch(s.exec, st));
+  } else {
+    Runner<T> r{h, &s.ln, st, R, s.Rp, s.maxN, s.S, 0, R, nullptr};
+    VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>()));
+  }
+  // the host arrays are reused by the next call: the copies above must have been consumed
+  VLG_HIP(hipStreamSynchronize(st));
+  return VLG_OK;
+}
+}  // namespace
+
+extern "C" int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp) {
+  VLG_CHECK(h && sp && rows > 0 && max_new_tokens > 0, VLG_ERR_BAD_ARG, "vlg_gpt_session_begin: bad argument");
+  VLG_CHECK(h->cfg.model_type == VLG_C2I && h->cfg.head == VLG_HEAD_LOGITS, VLG_ERR_UNSUPPORTED,
+            "sessions cover class-conditional token models (the reference's serving path, serve/sample_c2i.py)");
+  VLG_CHECK(h->Tc + max_new_tokens <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table", max_new_tokens);
+  for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
+  h->ses.reset();
+  return h->dtype == VLG_BF16 ? session_begin_impl<bf16>(h, rows, max_new_tokens, *sp) : session_begin_impl<float>(h, rows, max_new_tokens, *sp);
+}
+
+extern "C" int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class) {
+  VLG_CHECK(h && h_row_class, VLG_ERR_BAD_ARG, "vlg_gpt_session_step: null argument");
+  VLG_CHECK(h->ses != nullptr, VLG_ERR_STATE, "no open session");
+  return h->dtype == VLG_BF16 ? session_step_impl<bf16>(h, h_row_class) : session_step_impl<float>(h, h_row_class);
+}
+
+extern "C" int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out) {
+  VLG_CHECK(h && h_out && h->ses != nullptr, VLG_ERR_BAD_ARG, "vlg_gpt_session_read: bad argument / no open session");
+  vlg_gpt::Session& s = *h->ses;
+  VLG_CHECK(row >= 0 && row < s.R && n_tokens >= 0 && n_tokens <= s.maxN, VLG_ERR_BAD_ARG, "vlg_gpt_session_read: row %d / %d tokens out of range",
+            row, n_tokens);
+  VLG_HIP(hipStreamSynchronize(s.ln.st));
+  VLG_HIP(hipMemcpy(h_out, s.out_ids.as<int32_t>() + (size_t)row * s.maxN, (size_t)n_tokens * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_session_end(vlg_gpt_t* h) {
+  VLG_CHECK(h, VLG_ERR_BAD_ARG, "vlg_gpt_session_end: null handle");
+  if (h->ses) VLG_HIP(hipStreamSynchronize(h->ses->ln.st));
+  h->ses.reset();
+  return VLG_OK;
+}
 
 extern "C" int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, int32_t B, int32_t N,
                                 const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids, float* d_out_lat,

@@ -8,7 +8,12 @@ namespace vlg {
 struct StepState {
   int32_t pos;    // absolute input position of the current step's query rows (first row when Tq > 1)
   int32_t step;   // index of the token being produced (0 = prefill output)
+  // iteration-level batching (vlg_gpt_session_*): every batch row at its own position / token index.  Null = uniform (pos, step).
+  const int32_t* row_pos;
+  const int32_t* row_step;
 };
+__device__ __forceinline__ int state_pos(const StepState* s, int b) { return s->row_pos ? s->row_pos[b] : s->pos; }
+__device__ __forceinline__ int state_step(const StepState* s, int b) { return s->row_step ? s->row_step[b] : s->step; }
 
 enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_SILU = 2 };
 
@@ -163,6 +168,10 @@ int dl_finish(const T* x, float* cur, float* out_lat, float* trace, const StepSt
 
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
+int set_row_state(StepState* state, const int32_t* row_pos, const int32_t* row_step, hipStream_t st);   // per-row mode, device arrays
+template <typename T>
+int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok, T* out,
+                        int rows, int D, hipStream_t st);
 
 // sampler (sampler.hip) -----------------------------------------------------------------------
 // logits fp32 [Bp, V]; writes out_ids[b*N + step] (if out_ids), cur_tok[b] (and [b+B] when cfg_on),

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
   const int sec = col / D, within = col % D;
   const int hh = within / hd, d = within % hd;
   const int b = m / Tq, t = m % Tq;
-  const int p = state->pos + t;
+  const int p = state_pos(state, b) + t;
   float x0 = 0.f, x1 = 0.f;
   float2 part[8];
 #pragma unroll
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
   const int b = m / Tq, t = m % Tq;
-  const int p = state->pos + t;
+  const int p = state_pos(state, b) + t;
   const int nkeys = p + 1;
   const int chunk = (nkeys + nsplit - 1) / nsplit;
   const int r0 = split * chunk;
@@ -1190,6 +1190,33 @@ template int latent_out_fc2<float>(const float*, const float*, float*, float*, f
 template int latent_out_fc2<bf16>(const bf16*, const bf16*, float*, float*, float*, const StepState*, int, int, int, int, int, float, int,
                                   hipStream_t, int, int);
 
+// iteration-level batching: row m starts a request (row_cls[m] >= 0: its class embedding, the position-0 input of a c2i sequence)
+// or continues one (row_cls[m] < 0: the embedding of the token it sampled in the previous iteration)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_session_rows_kernel(const T* __restrict__ cls_table, int n_cls, const T* __restrict__ tok_table,
+                                                                  int n_tok, const int32_t* __restrict__ row_cls,
+                                                                  const int32_t* __restrict__ cur_tok, T* __restrict__ out, int D) {
+  const int m = blockIdx.x;
+  const int c = row_cls[m];
+  const T* src;
+  if (c >= 0) {
+    src = cls_table + (size_t)(c < n_cls ? c : n_cls - 1) * D;
+  } else {
+    int tk = cur_tok[m];
+    tk = tk < 0 ? 0 : (tk >= n_tok ? n_tok - 1 : tk);
+    src = tok_table + (size_t)tk * D;
+  }
+  for (int i = threadIdx.x; i < D; i += 256) out[(size_t)m * D + i] = src[i];
+}
+template <typename T>
+int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok, T* out,
+                        int rows, int D, hipStream_t st) {
+  gather_session_rows_kernel<T><<<rows, 256, 0, st>>>(cls_table, n_cls, tok_table, n_tok, row_cls, cur_tok, out, D);
+  return VLG_OK;
+}
+template int gather_session_rows<float>(const float*, int, const float*, int, const int32_t*, const int32_t*, float*, int, int, hipStream_t);
+template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, bf16*, int, int, hipStream_t);
+
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;
   s->step += 1;
@@ -1201,6 +1228,18 @@ int advance_state(StepState* state, hipStream_t st) {
 __global__ void set_state_kernel(StepState* s, int pos, int step) {
   s->pos = pos;
   s->step = step;
+  s->row_pos = nullptr;
+  s->row_step = nullptr;
+}
+__global__ void set_row_state_kernel(StepState* s, const int32_t* row_pos, const int32_t* row_step) {
+  s->pos = 0;
+  s->step = 0;
+  s->row_pos = row_pos;
+  s->row_step = row_step;
+}
+int set_row_state(StepState* state, const int32_t* row_pos, const int32_t* row_step, hipStream_t st) {
+  set_row_state_kernel<<<1, 1, 0, st>>>(state, row_pos, row_step);
+  return VLG_OK;
 }
 int set_state(StepState* state, int pos, int step, hipStream_t st) {
   set_state_kernel<<<1, 1, 0, st>>>(state, pos, step);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   __shared__ Smem sm;
   const int b = blockIdx.x, t = threadIdx.x;
-  const int step = state ? state->step : fixed_step;
+  const int step = state ? state_step(state, b) : fixed_step;
 
   // ---- 1. load, CFG combine, temperature ------------------------------------------------------------
   const bool cfg_flag = cfg_on && !(cfg_interval > -1 && (step - 1) > cfg_interval);

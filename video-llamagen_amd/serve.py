@@ -8,11 +8,13 @@ sampler.py:46-125 classifier-free guidance inside the sampler, sample_c2i.py:33-
     outs = llm.generate(prompt_token_ids=[[c] for c in labels] + [[1000]] * len(labels), sampling_params=sp, use_tqdm=False)
     ids = [o.outputs[0].token_ids for o in outs]
 
-Scheduling.  Every request of this workload produces exactly `max_tokens` tokens and stops, so iteration-level ("continuous") batching
-has nothing to reclaim inside a batch: sequences that start together end together.  The scheduler therefore works on WAVES: `step()`
-takes up to `max_num_seqs` waiting requests with identical sampling parameters, runs them through `vlg_gpt_generate` as one batch (KV
-cache sized for the wave, one hipGraph per decode step) and finishes them all; requests that arrived meanwhile join the next wave.
-Per-row positions inside one batch (a request joining mid-flight) are not implemented and would only matter for mixed `max_tokens`.
+Scheduling.  Two engines share the call surface:
+* `LLMEngine` (default of `LLM`): WAVES.  Every request of the reference's workload produces exactly `max_tokens` tokens, so sequences
+  that start together end together; `step()` takes up to `max_num_seqs` waiting requests with identical sampling parameters, runs
+  them through `vlg_gpt_generate` as one batch and finishes them all.
+* `ContinuousLLMEngine` (`LLM(..., continuous=True)`): ITERATION-LEVEL batching over `vlg_gpt_session_*` - a fixed set of KV-cache slots,
+  every `step()` advances each occupied slot by one token at its own position; a finished request frees its slot and a waiting one
+  (any `max_tokens` up to the session's) starts in it on the next step, mid-flight of the others.  One hipGraph per session.
 
 Classifier-free guidance follows sampler.py:54-58,106-108: with `args.cfg_scale > 1` the second half of the prompts are the null-class
 rows; logits are combined `u + (c - u) * s`, one token is drawn per pair and written to both members.  Here the pair shares one row of
@@ -171,12 +173,112 @@ class LLMEngine:
         return outs
 
 
+class ContinuousLLMEngine:
+    """Iteration-level scheduler (vLLM's scheduler + model runner loop, llm_engine.py `step`): slots instead of waves.  All requests of
+    a session share the sampling parameters of the first one except `max_tokens` (<= the session's)."""
+
+    def __init__(self, model, cfg_scale=1.0, cfg_interval=-1, max_num_seqs=256, seed=0, max_tokens=None):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.model = model
+        self.cfg_scale, self.cfg_interval, self.seed = float(cfg_scale), cfg_interval, seed
+        self.cfg = self.cfg_scale > 1.0
+        self.null_token = model.num_classes
+        self.slots_n = max(1, max_num_seqs // 2 if self.cfg else max_num_seqs)
+        self.max_tokens = max_tokens
+        self.waiting = collections.deque()
+        self.pending_null = collections.deque()      # null-class partner requests (reported with their partner's tokens)
+        self.slots = [None] * self.slots_n           # (request, tokens done, partner request or None)
+        self._open = False
+        self._params = None
+        self.steps_run = 0
+
+    def add_request(self, request_id, prompt, sampling_params, prompt_token_ids=None, **_):
+        if prompt_token_ids is None or len(prompt_token_ids) != 1:
+            raise ValueError("class-conditional prompts hold exactly one class id")
+        r = _Request(str(request_id), list(prompt_token_ids), sampling_params or SamplingParams(), time.time())
+        if self.cfg and r.prompt_token_ids[0] == self.null_token:
+            self.pending_null.append(r)
+        else:
+            self.waiting.append(r)
+
+    def get_num_unfinished_requests(self):
+        return len(self.waiting) + len(self.pending_null) + sum(1 + (s[2] is not None) for s in self.slots if s)
+
+    def has_unfinished_requests(self):
+        return bool(self.waiting) or any(self.slots)
+
+    def _begin(self, sp):
+        L, C = self._L, self._C
+        self.model._ensure_handle()
+        n = self.max_tokens or max([sp.max_tokens] + [r.params.max_tokens for r in self.waiting])
+        c = L.SamplingParams(cfg_scale=self.cfg_scale, cfg_interval=int(self.cfg_interval), temperature=float(sp.temperature),
+                             top_k=0 if sp.top_k == -1 else int(sp.top_k), top_p=float(sp.top_p), sample_logits=1 if sp.temperature > 0 else 0,
+                             seed=int(sp.seed if sp.seed is not None else self.seed))
+        with torch.cuda.device(self.model._device):
+            L.check(L.lib().vlg_gpt_session_begin(self.model._handle, self.slots_n, n, C.byref(c)))
+        self._open, self._params, self.session_tokens = True, sp, n
+
+    def close(self):
+        if self._open:
+            self._L.check(self._L.lib().vlg_gpt_session_end(self.model._handle))
+            self._open = False
+
+    def step(self) -> List[RequestOutput]:
+        L, C = self._L, self._C
+        if not self._open:
+            if not self.waiting:
+                return []
+            self._begin(self.waiting[0].params)
+        row_class = (C.c_int32 * self.slots_n)()
+        for i, s in enumerate(self.slots):
+            if s is not None:
+                row_class[i] = -1                                   # continue
+                continue
+            row_class[i] = -2                                       # idle unless a waiting request fits
+            if self.waiting:
+                r = self.waiting[0]
+                if r.params.max_tokens > self.session_tokens:
+                    raise ValueError("request %s asks for %d tokens, the session holds %d" % (r.request_id, r.params.max_tokens, self.session_tokens))
+                if self.cfg and not self.pending_null:
+                    continue                                        # its null-class partner has not arrived yet
+                self.waiting.popleft()
+                partner = self.pending_null.popleft() if self.cfg else None
+                self.slots[i] = [r, 0, partner]
+                row_class[i] = r.prompt_token_ids[0]
+        if not any(self.slots):
+            if self.waiting:
+                raise ValueError("classifier-free guidance needs one null-class prompt [[%s]] per conditional prompt" % self.null_token)
+            return []
+        with torch.cuda.device(self.model._device):
+            L.check(L.lib().vlg_gpt_session_step(self.model._handle, row_class))
+        self.steps_run += 1
+        outs = []
+        for i, s in enumerate(self.slots):
+            if s is None:
+                continue
+            s[1] += 1
+            r, done, partner = s
+            if done == r.params.max_tokens:
+                buf = (C.c_int32 * done)()
+                L.check(L.lib().vlg_gpt_session_read(self.model._handle, i, done, buf))
+                toks = list(buf)
+                outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, toks)]))
+                if partner is not None:
+                    outs.append(RequestOutput(partner.request_id, None, partner.prompt_token_ids, [CompletionOutput(0, list(toks))]))
+                self.slots[i] = None
+        if not self.has_unfinished_requests():
+            self.close()
+        return outs
+
+
 class LLM:
     """llm.py:20-267.  `model` names the GPT size ("GPT-XL" or a path ending in "GPT-XL.json", the reference's fake_json convention);
     `args` carries gpt_ckpt / gpt_type / cfg_scale / precision / image_size / downsample_size / num_classes / cls_token_num / from_fsdp."""
 
     def __init__(self, args, model, skip_tokenizer_init=True, seed=0, gpu_memory_utilization=0.9, max_num_seqs=256, dtype="auto",
-                 device="cuda", **kwargs):
+                 device="cuda", continuous=False, **kwargs):
         name = model.split("/")[-1]
         name = name[:-5] if name.endswith(".json") else name
         if name not in GPT_models:
@@ -190,8 +292,9 @@ class LLM:
         gpt = gpt.to(device=device, dtype=precision)
         self.weights = load_or_init(gpt, getattr(args, "gpt_ckpt", None), seed)
         gpt.eval()
-        self.llm_engine = LLMEngine(gpt, cfg_scale=getattr(args, "cfg_scale", 1.0), cfg_interval=getattr(args, "cfg_interval", -1),
-                                    max_num_seqs=max_num_seqs, seed=seed)
+        engine = ContinuousLLMEngine if continuous else LLMEngine
+        self.llm_engine = engine(gpt, cfg_scale=getattr(args, "cfg_scale", 1.0), cfg_interval=getattr(args, "cfg_interval", -1),
+                                 max_num_seqs=max_num_seqs, seed=seed)
         self._counter = 0
 
     def generate(self, prompts=None, sampling_params: Optional[Union[SamplingParams, List[SamplingParams]]] = None,
