@@ -465,3 +465,23 @@ def test_generate_edge_shapes():
     cls = np.array([0, cases.TINY_C2I["num_classes"] - 1], np.int64)           # first and last class id; null class = num_classes
     ids = V.generate(mc, torch.from_numpy(cls), 1, cfg_scale=1.5, sample_logits=False)
     assert (ids.cpu().numpy() == O.generate(omc, cls, 1, cfg_scale=1.5, sample_logits=False)).all()
+
+
+def test_gpt_xl_full_size_first_tokens_vs_oracle():
+    """BASELINE config 4 at its real size - GPT-XL (36 layers, D 1280, 20 heads, F 3584), 120 text tokens, t2v adapter2 head, 5x32x32
+    latent grid - against the numpy oracle on the same deterministic weights: prefill + 3 decode steps, 2 samples with ragged
+    masks.  fp32 handle within 2e-3 of the output range; bf16 handle (the benchmark's kernels) within 8e-2 on the first token."""
+    import video_llamagen_amd as V
+    cfg = dict(cases.GPT_SIZES["GPT-XL"], vocab_size=16384, block_size=1024, cls_token_num=120, model_type="t2v", num_classes=1000,
+               caption_dim=2048, norm_eps=1e-5, rope_base=10000.0, multiple_of=256, vae_embed_dim=8, num_frames=17, t_downsample_size=4,
+               head="adapter2", adapter_in_std=0.3, adapter_out_std=0.3)
+    sd = detweights.gpt_weights(cfg)
+    c, mk = cases.text_cond(2, 120, 2048, lens=[17, 120])
+    ref = O.generate_t2v(O.GPTOracle(cfg, sd, "fp32"), c, 4, mk)
+    scale = max(1.0, np.abs(ref).max())
+    for dt, tol, upto in ((torch.float32, 2e-3, 4), (torch.bfloat16, 8e-2, 1)):
+        m, unexpected = product_gpt(cfg, dt, sd=sd)
+        lat = to_np(V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk)))
+        assert lat.shape == ref.shape == (2, 4, 8)
+        assert np.abs(lat[:, :upto] - ref[:, :upto]).max() < tol * scale, (dt, np.abs(lat - ref).max(axis=(0, 2)))
+        del m
