@@ -275,3 +275,25 @@ def test_vae_full_size_batch_invariance():
     assert tuple(both.shape) == (2, 3, 17, 256, 256) and torch.isfinite(both.float()).all()
     assert torch.equal(both[0:1], vae.decode(z[0:1])) and torch.equal(both[1:2], vae.decode(z[1:2]))
     assert not torch.equal(both[0], both[1])
+
+
+def test_vae_full_width_vs_oracle():
+    """CausalVAEModel constructor defaults (hidden 128, mult (1,2,4,4): the 512/256/128-channel convolutions of BASELINE config 4, 16
+    channel chunks per tap in the halo kernel) on a [1,8,2,8,8] latent -> [1,3,5,64,64], against the numpy oracle on the same weights."""
+    import video_llamagen_amd as V
+    cfg = dict(hidden_size=128, z_channels=4, embed_dim=8, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2)
+    sd = detweights.vae_weights(cfg)
+    z = cases.rng(5).standard_normal((1, 8, 2, 8, 8), dtype=np.float32)
+    ref = O.VAEOracle(sd, hidden_size=128, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2).decode(z)
+    scale = np.abs(ref).max()
+    for dt in (torch.float32, torch.bfloat16):
+        m = V.VAE_models["VAE-16"](embed_dim=8).to("cuda", dt)
+        _, skipped = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        assert skipped == []
+        y = to_np(m.decode(torch.from_numpy(z)))
+        assert y.shape == ref.shape == (1, 3, 5, 64, 64)
+        err = np.abs(y - ref)
+        if dt == torch.float32:
+            assert err.max() < 2e-3 * scale
+        else:
+            assert err.max() < 6e-2 * scale and np.sqrt((err ** 2).mean()) < 1.5e-2 * scale
