@@ -164,10 +164,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
   int epos = 0;
-  const int32_t* erow_pos = nullptr;   // iteration-level batching: per-row positions (StepState::row_pos)
+  const int32_t* erow_pos = nullptr;   // iteration-level batching: per-row positions (a kernel argument, no dependent load)
   if constexpr (EPI == EPI_QKV) {
-    epos = fa.state->pos;   // scalar loads
-    erow_pos = fa.state->row_pos;
+    epos = fa.state->pos;   // scalar load
+    erow_pos = fa.row_pos;
   }
   auto epilogue_operands = [&]() {
     if constexpr (EPI == EPI_RESID || EPI == EPI_GATED) {
@@ -186,8 +186,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
         row = row < M ? row : M - 1;
-        const int pp = (erow_pos ? erow_pos[row / fa.Tq] : epos) + row % fa.Tq;
-        const float* cp = fa.freqs + ((size_t)pp * (fa.hd / 2) + d / 2) * 2;
+        // uniform position: sessions (per-row positions) reload their pair in the epilogue - a per-row load here would put a
+        // branch and a dependent load in front of the weight stream
+        const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
         ecx[mt] = cp[0];
         ecy[mt] = cp[1];
       }
@@ -398,7 +399,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
       float o = xs;
       if (sec < 2) {
-        const float cx = ecx[mt], cy = ecy[mt];
+        float cx = ecx[mt], cy = ecy[mt];
+        if (erow_pos) {
+          const float* cp = fa.freqs + ((size_t)p * (fa.hd / 2) + d / 2) * 2;
+          cx = cp[0];
+          cy = cp[1];
+        }
         o = (d & 1) ? __fadd_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy))    // x1*c + x0*s
                     : __fsub_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy));   // x0*c - x1*s
       }

@@ -406,6 +406,8 @@ struct Runner {
   int b0, Btot;        // first sample of the lane within the call's batch, call batch
   const float* mask;   // device [B, Tc] (lane slice) or null
   int ev_slot = -1;    // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
+  const int32_t* row_pos = nullptr;    // sessions: per-row positions / token indices (device arrays); null = uniform StepState
+  const int32_t* row_step = nullptr;
   StepState* state() { return ln->state.as<StepState>(); }
   int* attn_cnt() { return h->attn_inlaunch ? ln->attn_cnt.as<int>() : nullptr; }
   template <typename U>
@@ -434,14 +436,14 @@ struct Runner {
       T* vc = ln->vcache.as<T>() + lstride * l;
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
       const bool fused = (Tq == 1) && h->fuse_qkv;
-      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st));
+      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt()));
+                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt(), row_pos));
       VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
@@ -484,6 +486,7 @@ struct Runner {
       fa.vc = vc;
       fa.freqs = h->freqs.as<float>();
       fa.state = state();
+      fa.row_pos = row_pos;
       fa.Tq = 1;
       fa.H = H;
       fa.hd = hd;
@@ -495,7 +498,7 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
-                           st, e0, e1, nullptr, 0, nullptr, attn_cnt()));
+                           st, e0, e1, nullptr, 0, nullptr, attn_cnt(), row_pos));
       FusedGemm fr;
       fr.h = x;
       if (h->splitk_inlaunch) {   // measured r01: the release/acquire pair costs more than the idle CUs (22.9 s vs 22.6 s/step)
@@ -524,7 +527,7 @@ struct Runner {
       fa.out_f32 = ln->logits.as<float>();
       VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("output.weight"), Bp, h->V, D, true, EPI_STORE, fa, st));
       return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
-                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot);
+                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot, row_step);
     }
     if (h->cfg.head == VLG_HEAD_ADAPTER2) {
       fa.out = ln->t1.as<T>();
@@ -550,7 +553,7 @@ struct Runner {
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       VLG_TRY(linear(hl, "output.weight", nullptr, ln->logits.as<float>(), Bp, h->V, D, ACT_NONE));
       return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
-                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot);
+                         ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot, row_step);
     }
     if (h->cfg.head == VLG_HEAD_ADAPTER2) {
       VLG_TRY(linear(hl, "vae_latent_adapter2.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, D, ACT_GELU_TANH));
@@ -1025,8 +1028,10 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   ses->h_step.assign(ses->Rp, 0);
   ses->h_cls.assign(ses->Rp, h->cfg.num_classes);
   hipStream_t st = ses->ln.st;
-  VLG_TRY(set_row_state(ses->ln.state.as<StepState>(), ses->row_pos.as<int32_t>(), ses->row_step.as<int32_t>(), st));
+  VLG_TRY(set_state(ses->ln.state.as<StepState>(), 0, 0, st));
   Runner<T> r{h, &ses->ln, st, R, ses->Rp, maxN, ses->S, 0, R, nullptr};
+  r.row_pos = ses->row_pos.as<int32_t>();
+  r.row_step = ses->row_step.as<int32_t>();
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1077,6 +1082,8 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
     VLG_HIP(hipGraphLaunch(s.exec, st));
   } else {
     Runner<T> r{h, &s.ln, st, R, s.Rp, s.maxN, s.S, 0, R, nullptr};
+    r.row_pos = s.row_pos.as<int32_t>();
+    r.row_step = s.row_step.as<int32_t>();
     VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>()));
   }
   // the host arrays are reused by the next call: the copies above must have been consumed

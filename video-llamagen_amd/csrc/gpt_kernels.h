@@ -8,12 +8,10 @@ namespace vlg {
 struct StepState {
   int32_t pos;    // absolute input position of the current step's query rows (first row when Tq > 1)
   int32_t step;   // index of the token being produced (0 = prefill output)
-  // iteration-level batching (vlg_gpt_session_*): every batch row at its own position / token index.  Null = uniform (pos, step).
-  const int32_t* row_pos;
-  const int32_t* row_step;
 };
-__device__ __forceinline__ int state_pos(const StepState* s, int b) { return s->row_pos ? s->row_pos[b] : s->pos; }
-__device__ __forceinline__ int state_step(const StepState* s, int b) { return s->row_step ? s->row_step[b] : s->step; }
+// Iteration-level batching (vlg_gpt_session_*): every batch row at its own position / token index.  The per-row arrays are KERNEL
+// ARGUMENTS (null = uniform mode): a pointer kept inside StepState would put a dependent load in front of every kernel's first
+// address computation (measured: +1 us on the QKV GEMM).
 
 enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_SILU = 2 };
 
@@ -40,6 +38,7 @@ struct FusedGemm {
   void* vc = nullptr;
   const float* freqs = nullptr;
   const StepState* state = nullptr;
+  const int32_t* row_pos = nullptr;   // EPI_QKV, sessions: position of batch row b instead of state->pos
   int Tq = 1, H = 0, hd = 0, S = 0;
   void* out = nullptr;            // EPI_SWIGLU: g [M,N]; EPI_STORE: out [M,N] (T)
   float* out_f32 = nullptr;       // EPI_STORE
@@ -96,7 +95,7 @@ int reduce_silu_mul(const float* ws, int splits, T* g, int M, int F, hipStream_t
 // caches: [Bp, H, S, hd]; rows m = b*Tq + t.  freqs: fp32 [npos, hd/2, 2]          (gpt.py:215-227)
 template <typename T>
 int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache, const float* freqs,
-                     const StepState* state, int M, int Tq, int H, int hd, int S, hipStream_t st);
+                     const StepState* state, int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos = nullptr);
 
 // attention of every query row m = b*Tq + t (position p = state->pos + t) over keys 0..p of batch b
 // (gpt.py:230-237 with the mask of generate.py:156-165).  out [M, H*hd].
@@ -110,7 +109,8 @@ int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, co
               const float* qkv_ws = nullptr, int qkv_splits = 0, const float* freqs = nullptr,
               // counters != null: the splits are merged inside the launch by the last-arriving workgroup of each (row, head)
               // (no attn_combine launch).  M*H ints, zero before the first launch; every launch leaves them zero.
-              int* counters = nullptr);
+              int* counters = nullptr,
+              const int32_t* row_pos = nullptr);   // sessions: batch row b attends keys 0..row_pos[b] (+t)
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------
@@ -168,7 +168,6 @@ int dl_finish(const T* x, float* cur, float* out_lat, float* trace, const StepSt
 
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
-int set_row_state(StepState* state, const int32_t* row_pos, const int32_t* row_step, hipStream_t st);   // per-row mode, device arrays
 template <typename T>
 int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok, T* out,
                         int rows, int D, hipStream_t st);
@@ -178,7 +177,7 @@ int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n
 // trace[step][b][V] (if trace), probs[b][V] (if probs).  noise: fp32 [N or 1][B][V] indexed by step.
 int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampling_params& sp, const float* noise,
                 const StepState* state, int fixed_step, int N, int32_t* out_ids, int32_t* cur_tok, float* trace,
-                float* probs, hipStream_t st, int b_off = 0, int B_total = 0);
+                float* probs, hipStream_t st, int b_off = 0, int B_total = 0, const int32_t* row_step = nullptr);
 // b_off / B_total: the rows are samples b_off.. of a B_total-sample call (batch lanes): noise, trace and the Philox
 // counter are indexed by the global sample id so results do not depend on the lane split.
 

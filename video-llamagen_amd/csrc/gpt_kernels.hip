@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
                                                                T* __restrict__ kc, T* __restrict__ vc,
                                                                const float* __restrict__ freqs,
                                                                const StepState* __restrict__ state, int M, int Tq, int H,
-                                                               int hd, int S) {
+                                                               int hd, int S, const int32_t* __restrict__ row_pos) {
   const int D = H * hd;
   const int pairs = 3 * D / 2;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
   const int sec = col / D, within = col % D;
   const int hh = within / hd, d = within % hd;
   const int b = m / Tq, t = m % Tq;
-  const int p = state_pos(state, b) + t;
+  const int p = (row_pos ? row_pos[b] : state->pos) + t;
   float x0 = 0.f, x1 = 0.f;
   float2 part[8];
 #pragma unroll
@@ -607,14 +607,16 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
 
 template <typename T>
 int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache, const float* freqs, const StepState* state,
-                     int M, int Tq, int H, int hd, int S, hipStream_t st) {
+                     int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos) {
   long long n = (long long)M * (3 * H * hd / 2);
   qkv_rope_scatter_kernel<T><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(ws, splits, qbuf, kcache, vcache, freqs, state,
-                                                                                M, Tq, H, hd, S);
+                                                                                M, Tq, H, hd, S, row_pos);
   return VLG_OK;
 }
-template int qkv_rope_scatter<float>(const float*, int, float*, float*, float*, const float*, const StepState*, int, int, int, int, int, hipStream_t);
-template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, const float*, const StepState*, int, int, int, int, int, hipStream_t);
+template int qkv_rope_scatter<float>(const float*, int, float*, float*, float*, const float*, const StepState*, int, int, int, int, int, hipStream_t,
+                                     const int32_t*);
+template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, const float*, const StepState*, int, int, int, int, int, hipStream_t,
+                                    const int32_t*);
 
 // ------------------------------------------------------------------------------------------------
 // split-KV attention for one query row per (row m, head h)
@@ -638,12 +640,13 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
-                                                           int Tc, float scale, FusedQKV fq, int* __restrict__ counters) {
+                                                           int Tc, float scale, FusedQKV fq, int* __restrict__ counters,
+                                                           const int32_t* __restrict__ row_pos) {
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
   const int b = m / Tq, t = m % Tq;
-  const int p = state_pos(state, b) + t;
+  const int p = (row_pos ? row_pos[b] : state->pos) + t;
   const int nkeys = p + 1;
   const int chunk = (nkeys + nsplit - 1) / nsplit;
   const int r0 = split * chunk;
@@ -897,7 +900,7 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                       const FusedQKV* fq, int* counters) {
+                       const FusedQKV* fq, int* counters, const int32_t* row_pos) {
   const int M = Bp * Tq;
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
   // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
@@ -914,7 +917,7 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
   if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
     if constexpr (VEC % 2 == 0)
       attn_partial_kernel<T, HD, VEC, LPR, true, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                      Tc, scale, *fq, counters);
+                                                                                      Tc, scale, *fq, counters, row_pos);
   } else {
     if (fq != nullptr) {
       set_error("fused qkv attention needs Tq == 1");
@@ -923,13 +926,13 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
     static const int u_knob = getenv("VLG_ATTN_U") ? atoi(getenv("VLG_ATTN_U")) : 4;
     if (u_knob == 8)
       attn_partial_kernel<T, HD, VEC, LPR, false, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
     else if (u_knob == 2)
       attn_partial_kernel<T, HD, VEC, LPR, false, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
     else
       attn_partial_kernel<T, HD, VEC, LPR, false, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters);
+                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (nsplit > 1 && counters == nullptr) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
@@ -939,11 +942,11 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
 template <typename T>
 int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
               int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters) {
+              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters, const int32_t* row_pos) {
   FusedQKV fqv{qkv_ws, qkv_splits, freqs};
   const FusedQKV* fq = qkv_ws ? &fqv : nullptr;
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters, row_pos)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -961,8 +964,8 @@ int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* s
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*);
-template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels
@@ -1228,18 +1231,6 @@ int advance_state(StepState* state, hipStream_t st) {
 __global__ void set_state_kernel(StepState* s, int pos, int step) {
   s->pos = pos;
   s->step = step;
-  s->row_pos = nullptr;
-  s->row_step = nullptr;
-}
-__global__ void set_row_state_kernel(StepState* s, const int32_t* row_pos, const int32_t* row_step) {
-  s->pos = 0;
-  s->step = 0;
-  s->row_pos = row_pos;
-  s->row_step = row_step;
-}
-int set_row_state(StepState* state, const int32_t* row_pos, const int32_t* row_step, hipStream_t st) {
-  set_row_state_kernel<<<1, 1, 0, st>>>(state, row_pos, row_step);
-  return VLG_OK;
 }
 int set_state(StepState* state, int pos, int step, hipStream_t st) {
   set_state_kernel<<<1, 1, 0, st>>>(state, pos, step);

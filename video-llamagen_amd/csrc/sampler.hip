@@ -84,11 +84,12 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
                                                     int sample_logits, uint64_t seed, const float* __restrict__ noise,
                                                     const StepState* __restrict__ state, int fixed_step, int N,
                                                     int32_t* __restrict__ out_ids, int32_t* __restrict__ cur_tok,
-                                                    float* __restrict__ trace, float* __restrict__ probs_out, int b_off, int B_total) {
+                                                    float* __restrict__ trace, float* __restrict__ probs_out, int b_off, int B_total,
+                                                    const int32_t* __restrict__ row_step) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   __shared__ Smem sm;
   const int b = blockIdx.x, t = threadIdx.x;
-  const int step = state ? state_step(state, b) : fixed_step;
+  const int step = row_step ? row_step[b] : (state ? state->step : fixed_step);
 
   // ---- 1. load, CFG combine, temperature ------------------------------------------------------------
   const bool cfg_flag = cfg_on && !(cfg_interval > -1 && (step - 1) > cfg_interval);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
 
 int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampling_params& sp, const float* noise,
                 const StepState* state, int fixed_step, int N, int32_t* out_ids, int32_t* cur_tok, float* trace, float* probs,
-                hipStream_t st, int b_off, int B_total) {
+                hipStream_t st, int b_off, int B_total, const int32_t* row_step) {
   if (B_total <= 0) B_total = B;
   if (V > VMAX || V < 1) {
     set_error("sampler: vocab %d not supported (max %d)", V, VMAX);
@@ -329,11 +330,11 @@ int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampli
     }
     sample_kernel<true><<<B, NT, dyn, st>>>(logits, B, V, cfg_on ? 1 : 0, sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k,
                                             sp.top_p, sp.sample_logits, sp.seed, noise, state, fixed_step, N, out_ids, cur_tok, trace,
-                                            probs, b_off, B_total);
+                                            probs, b_off, B_total, row_step);
   } else {
     sample_kernel<false><<<B, NT, 0, st>>>(logits, B, V, cfg_on ? 1 : 0, sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k,
                                            sp.top_p, sp.sample_logits, sp.seed, noise, state, fixed_step, N, out_ids, cur_tok, trace,
-                                           probs, b_off, B_total);
+                                           probs, b_off, B_total, row_step);
   }
   return VLG_OK;
 }
