@@ -428,6 +428,12 @@ def test_full_width_decode_paths_agree():
     m.attn_inlaunch = True             # split-KV partials merged by the last-arriving workgroup: same arithmetic, same order
     assert torch.equal(a, V.generate_t2v(m, cond, 40, mask))
     m.attn_inlaunch = False
+    # residual GEMMs with the K range split over workgroups and merged in-launch (off by default: slower): same sums, other order
+    from video_llamagen_amd import _lib
+    _lib.check(_lib.lib().vlg_gpt_set_option(m._handle, b"splitk_inlaunch", C.c_int64(1)))
+    sk = V.generate_t2v(m, cond, 40, mask)
+    _lib.check(_lib.lib().vlg_gpt_set_option(m._handle, b"splitk_inlaunch", C.c_int64(0)))
+    assert torch.isfinite(sk).all() and torch.equal(sk[:, 0], a[:, 0]) and (sk[:, :3] - a[:, :3]).abs().max().item() < 2e-2 * a.abs().max().item()
     m.fuse_gemm = False
     c = V.generate_t2v(m, cond, 40, mask)
     m.fuse_qkv = True

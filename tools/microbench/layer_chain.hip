@@ -45,6 +45,12 @@ int main(int argc, char** argv) {
   const int L = 36, D = 1280, F = 3584, H = 20, hd = 64, S = 8;
   const int reps = 30;
   const bool static_a = argc > 2 && atoi(argv[2]) == 1;   // experiment: prologue kernels read a never-written activation buffer
+  const bool splitk = argc > 3 && atoi(argv[3]) == 1;     // in-launch split-K for the two residual GEMMs
+  float* slabs = nullptr;
+  int* counters = nullptr;
+  CK(hipMalloc(&slabs, (size_t)1024 * 8 * 256 * 4 * sizeof(float)));
+  CK(hipMalloc(&counters, 1024 * sizeof(int)));
+  CK(hipMemset(counters, 0, 1024 * sizeof(int)));
   std::vector<bf16*> wqkv(L), wo(L), w13(L), w2(L), nw1(L), nw2(L);
   for (int l = 0; l < L; ++l) {
     wqkv[l] = alloc_fill((size_t)3 * D * D, 11 * l + 1, 0.04f);
@@ -86,6 +92,7 @@ int main(int argc, char** argv) {
       if (gemm_fused<bf16>(static_a ? x0 : x, wqkv[l], M, 3 * D, D, true, EPI_QKV, fa, st)) { fprintf(stderr, "qkv fail\n"); exit(1); }
       FusedGemm fb;
       fb.h = x;
+      if (splitk) { fb.slabs = slabs; fb.counters = counters; fb.max_tiles = 1024; }
       fb.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
       if (gemm_fused<bf16>(ao, wo[l], M, D, D, false, EPI_RESID, fb, st)) exit(1);
       FusedGemm fc;
@@ -95,6 +102,7 @@ int main(int argc, char** argv) {
       if (gemm_fused<bf16>(static_a ? x0 : x, w13[l], M, F, D, true, EPI_SWIGLU, fc, st)) exit(1);
       FusedGemm fd;
       fd.h = x;
+      if (splitk) { fd.slabs = slabs; fd.counters = counters; fd.max_tiles = 1024; }
       fd.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
       if (gemm_fused<bf16>(g, w2[l], M, D, F, false, EPI_RESID, fd, st)) exit(1);
     }

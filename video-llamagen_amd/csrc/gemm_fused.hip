@@ -317,9 +317,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   float part[MT];
   if constexpr (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE)) {
     if (splits > 1) {
-      // In-launch split-K combine (cdna_hip_programming.md §5 "In-launch split-K reduction"): every K-slice workgroup writes
-      // its fp32 tile, releases at agent scope, takes a ticket; the last arriver acquires, sums the slices in slice order
-      // (deterministic) and runs the epilogue.  The counter is reset by the last arriver (zeroed once at allocation).
+      // In-launch split-K combine (cdna_hip_programming.md §5 "In-launch split-K reduction", write-through form): every K-slice
+      // workgroup writes its fp32 tile with sc1 (agent-scope) stores, drains them and takes a ticket; the last arriver reads the
+      // slices back with sc1 loads in slice order (deterministic) and runs the epilogue.  No release / acquire fence: an
+      // agent-scope acquire invalidates the XCD's whole L2.  The counter is reset by the last arriver (zero at allocation).
       const int tile = by * gridDim.x + bx;
       float* slab = fa.slabs + ((size_t)tile * splits + split) * (MT * 256);
       if (t < 256) {
@@ -328,30 +329,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
           float v = 0.f;
 #pragma unroll
           for (int wv = 0; wv < NW; ++wv) v += red[wv][0][mt][t];
-          slab[mt * 256 + t] = v;
+          __hip_atomic_store(slab + mt * 256 + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ticket_sm = __hip_atomic_fetch_add(fa.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (t == 0) ticket_sm = __hip_atomic_fetch_add(fa.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       if (ticket_sm != splits - 1) return;
-      if (t == 0) {
-        __hip_atomic_store(fa.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
+      if (t == 0) __hip_atomic_store(fa.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t < 256) {
         const float* base = fa.slabs + (size_t)tile * splits * (MT * 256);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           float v = 0.f;
-          for (int sp2 = 0; sp2 < splits; ++sp2) v += base[(size_t)sp2 * (MT * 256) + mt * 256 + t];
+          for (int sp2 = 0; sp2 < splits; ++sp2)
+            v += __hip_atomic_load(base + (size_t)sp2 * (MT * 256) + mt * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           part[mt] = v;
         }
       }
@@ -621,23 +614,20 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
   const int nkb_all = K / KB<T>::KBLK;
   // few n-tiles (N = D: wo, w2): 16-row workgroups, so twice the CUs stream and each pulls half the activations through its
   // vector-memory pipe (the row halves of a tile share an XCD, see the kernel); 8 waves when K needs more than 16 K-block slots
-  const bool rows16 = !pro && (epi == EPI_RESID || epi == EPI_GATED || epi == EPI_STORE) && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0 &&
-                      !(fa.slabs && fa.counters);
+  const bool rows16 = !pro && (epi == EPI_RESID || epi == EPI_GATED || epi == EPI_STORE) && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0;
   if (rows16) mt = 1;
-  const bool wide = (mt * nh >= 4) || (rows16 && nkb_all > 16);   // 8 waves so one pass of the K loop covers the whole K range
   int splits = 1;
   if (!pro && (epi == EPI_RESID || epi == EPI_STORE) && fa.slabs && fa.counters) {
-    // few n-tiles (N = D): split K over workgroups so every CU streams weights; combined in-launch by the last arriver
+    // few n-tiles (N = D): K split over workgroups as well, combined in-launch by the last arriver
     const int tiles = (N / 16) * cdiv(M, mt * 16);
-    const int nw = (mt == 4 || wide) ? 8 : 4;
-    const int nkb = K / KB<T>::KBLK;
-    splits = (240 + tiles / 2) / tiles;
-    const int maxs = (nkb + nw - 1) / nw;
+    splits = (320 + tiles / 2) / tiles;
+    const int maxs = nkb_all / 4;
     if (splits > maxs) splits = maxs;
     if (splits > 8) splits = 8;
     if (splits < 1) splits = 1;
     if (tiles > fa.max_tiles) splits = 1;
   }
+  const bool wide = (mt * nh >= 4) || (rows16 && cdiv(nkb_all, splits) > 16);   // 8 waves so one pass of the K loop covers the slice
   dim3 grid(N / 16, cdiv(M, mt * 16), splits);
 #define VLG_GF(MT_, NW_)                                                            \
   do {                                                                              \
