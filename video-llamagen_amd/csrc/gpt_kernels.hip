@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x,
 // register-staged, 16-byte-chunk XOR swizzle); each wave streams only its own weight rows (non-temporal): 1 : 1.
 // Output: fp32 slabs like gemm_mfma_kernel (gridDim.z K-slices), consumed by the reduce_* kernels.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool NT>   // NT: non-temporal weight loads (one row block: every weight byte is read once)
 __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x, const T* __restrict__ w, float* __restrict__ slabs, int M,
                                                         int N, int K) {
   constexpr int KBLK = GemmT<T>::KBLK;   // 256 bytes per row per K block for both dtypes
@@ -258,7 +258,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kb * CPB];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) b[s2] = __builtin_nontemporal_load(wsrc + (size_t)kb * CPB + s2 * 4);
+    for (int s2 = 0; s2 < 4; ++s2) {
+      if constexpr (NT)
+        b[s2] = __builtin_nontemporal_load(wsrc + (size_t)kb * CPB + s2 * 4);
+      else
+        b[s2] = wsrc[(size_t)kb * CPB + s2 * 4];   // several row blocks (prefill) re-read the tile: let L2 keep it
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) As[0][aslot[i]] = ra[i];
   }
@@ -271,7 +276,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kl * CPB];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) bn[s2] = __builtin_nontemporal_load(wsrc + (size_t)kl * CPB + s2 * 4);
+    for (int s2 = 0; s2 < 4; ++s2) {
+      if constexpr (NT)
+        bn[s2] = __builtin_nontemporal_load(wsrc + (size_t)kl * CPB + s2 * 4);
+      else
+        bn[s2] = wsrc[(size_t)kl * CPB + s2 * 4];
+    }
     u32x4_t af[4][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -368,7 +378,10 @@ int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* spli
     return VLG_OK;
   }
   if (wide) {
-    gemm_wide_kernel<T><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
+    if (mchunks == 1)
+      gemm_wide_kernel<T, true><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
+    else
+      gemm_wide_kernel<T, false><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
     *splits_out = splits;
     return VLG_OK;
   }
