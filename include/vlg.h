@@ -217,6 +217,26 @@ int vlg_vae_out_shape(vlg_vae_t* h, int32_t t, int32_t hh, int32_t ww, int32_t* 
  * d_x fp32 [B,3,T,H,W] -> d_moments fp32 [B, 2*embed_dim, (T-1)/4+1, H/8, W/8] = [mean | logvar]                      */
 int vlg_vae_encode(vlg_vae_t* h, const float* d_x, int32_t B, int32_t T_, int32_t Hh, int32_t Ww, float* d_moments, void* stream);
 
+/* ---- T5 text encoder: the conditioning step in front of t2i / t2v (language/t5.py:60-81 -> transformers.T5EncoderModel) ------
+ * State-dict names are transformers' ("shared.weight", "encoder.block.{i}.layer.0.SelfAttention.{q,k,v,o}.weight",
+ * "...layer.0.SelfAttention.relative_attention_bias.weight" (block 0), "...layer.{0,1}.layer_norm.weight",
+ * "...layer.1.DenseReluDense.{wi_0,wi_1,wo}.weight", "encoder.final_layer_norm.weight").
+ * encode: input_ids int64 [B,T], attention_mask fp32 [B,T] (1 = token, language/t5.py:66-74) -> last_hidden_state fp32 [B,T,d_model] */
+typedef struct vlg_t5 vlg_t5_t;
+typedef struct {
+  int32_t d_model, d_kv, num_heads, d_ff, num_layers, vocab_size;
+  int32_t relative_attention_num_buckets, relative_attention_max_distance;
+  int32_t gated_gelu;            /* 1: feed_forward_proj = "gated-gelu" (flan-t5, t5-v1_1); the only form built */
+  int32_t dtype;
+  float layer_norm_epsilon;
+} vlg_t5_config;
+int vlg_t5_create(const vlg_t5_config* cfg, vlg_t5_t** out);
+int vlg_t5_destroy(vlg_t5_t* h);
+int vlg_t5_load_tensor(vlg_t5_t* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                       int32_t src_dtype, int32_t src_on_device, int32_t* consumed);
+int vlg_t5_encode(vlg_t5_t* h, const int64_t* d_input_ids, const float* d_attention_mask, int32_t B, int32_t T,
+                  float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

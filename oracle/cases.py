@@ -15,6 +15,10 @@ TINY_T2V_DIFF = dict(TINY_T2V, head="hidden", diffloss_w=128, diffloss_d=3, num_
 # hd = 100 (GPT-3B's head_dim, gpt.py:445) at toy width
 TINY_HD100 = dict(TINY_C2I, dim=200, n_head=2, block_size=16)
 
+# transformers.T5Config fields; flan-t5-xl (the reference's text encoder, language/t5.py:16): d_model 2048, d_kv 64, 32 heads, d_ff 5120, 24 layers
+TINY_T5 = dict(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=2, vocab_size=100, relative_attention_num_buckets=32,
+               relative_attention_max_distance=128, layer_norm_epsilon=1e-6, feed_forward_proj="gated-gelu")
+
 GPT_B = dict(dim=768, n_layer=12, n_head=12, vocab_size=16384, block_size=256, cls_token_num=1,
              model_type="c2i", num_classes=1000, caption_dim=2048, norm_eps=1e-5, rope_base=10000.0,
              multiple_of=256, head="logits")

@@ -324,3 +324,25 @@ def videovq_weights(cfg=None, seed=1234):
         sd[f"decoder.convts.{i}.convt.weight"] = normal(f"decoder.convts.{i}.convt.weight", (nh, co, 4, 4, 4), 1.0 / np.sqrt(nh * 8), seed)
         sd[f"decoder.convts.{i}.convt.bias"] = normal(f"decoder.convts.{i}.convt.bias", (co,), 0.02, seed)
     return sd
+
+
+def t5_weights(cfg, seed=1234):
+    """transformers.T5EncoderModel state-dict names (gated-GELU feed-forward), init roughly as T5PreTrainedModel._init_weights."""
+    D, dk, H, F_, V = cfg["d_model"], cfg["d_kv"], cfg["num_heads"], cfg["d_ff"], cfg["vocab_size"]
+    inner = H * dk
+    sd = {"shared.weight": normal("shared.weight", (V, D), 1.0, seed)}
+    sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = normal(
+        "t5.rel_bias", (cfg["relative_attention_num_buckets"], H), 0.5, seed)
+    for l in range(cfg["num_layers"]):
+        p = f"encoder.block.{l}.layer."
+        sd[p + "0.SelfAttention.q.weight"] = normal(p + "q", (inner, D), (D * dk) ** -0.5 * 2.0, seed)
+        sd[p + "0.SelfAttention.k.weight"] = normal(p + "k", (inner, D), D ** -0.5, seed)
+        sd[p + "0.SelfAttention.v.weight"] = normal(p + "v", (inner, D), D ** -0.5, seed)
+        sd[p + "0.SelfAttention.o.weight"] = normal(p + "o", (D, inner), inner ** -0.5, seed)
+        sd[p + "0.layer_norm.weight"] = (1.0 + 0.1 * normal(p + "ln0", (D,), 1.0, seed)).astype("float32")
+        sd[p + "1.DenseReluDense.wi_0.weight"] = normal(p + "wi0", (F_, D), D ** -0.5, seed)
+        sd[p + "1.DenseReluDense.wi_1.weight"] = normal(p + "wi1", (F_, D), D ** -0.5, seed)
+        sd[p + "1.DenseReluDense.wo.weight"] = normal(p + "wo", (D, F_), F_ ** -0.5, seed)
+        sd[p + "1.layer_norm.weight"] = (1.0 + 0.1 * normal(p + "ln1", (D,), 1.0, seed)).astype("float32")
+    sd["encoder.final_layer_norm.weight"] = (1.0 + 0.1 * normal("t5.final_ln", (D,), 1.0, seed)).astype("float32")
+    return sd

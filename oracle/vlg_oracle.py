@@ -942,3 +942,57 @@ class VideoVQVAEOracle:
                 h = np.maximum(h, 0)
             i += 1
         return h
+
+
+# ----------------------------------------------------------------------------
+# T5 text encoder: the conditioning step in front of the t2i / t2v path (language/t5.py:60-81).
+# The reference wraps the third-party `transformers.T5EncoderModel` (flan-t5-xl / t5-v1_1-xxl: gated-GELU feed-forward); the algorithm
+# restated here is that library's (modeling_t5.py: T5LayerNorm, T5Attention with bucketed relative position bias and NO 1/sqrt(d)
+# scaling, T5DenseGatedActDense with gelu_new, pre-norm residual blocks, final layer norm), pinned by goldens generated from the
+# installed transformers (5.15.0) on CPU.
+# ----------------------------------------------------------------------------
+def t5_relative_bucket(rel, num_buckets=32, max_distance=128):
+    """modeling_t5.py `_relative_position_bucket`, bidirectional: rel = key position - query position."""
+    rel = np.asarray(rel, dtype=np.int64)
+    nb = num_buckets // 2
+    ret = (rel > 0).astype(np.int64) * nb
+    n = np.abs(rel)
+    max_exact = nb // 2
+    small = n < max_exact
+    with np.errstate(divide="ignore"):
+        large = max_exact + (np.log(np.maximum(n, 1).astype(F32) / F32(max_exact)) / F32(math.log(max_distance / max_exact))
+                             * F32(nb - max_exact)).astype(np.int64)
+    large = np.minimum(large, nb - 1)
+    return ret + np.where(small, n, large)
+
+
+class T5Oracle:
+    def __init__(self, cfg, sd, dt="fp32"):
+        self.cfg, self.sd, self.dt = cfg, sd, dt
+
+    def encode(self, ids, mask):
+        """ids int [B,T], mask [B,T] (1 = token) -> last_hidden_state [B,T,d_model]."""
+        c, sd, dt = self.cfg, self.sd, self.dt
+        H, dk, eps = c["num_heads"], c["d_kv"], F32(c.get("layer_norm_epsilon", 1e-6))
+        B, T = ids.shape
+        h = rt(sd["shared.weight"][ids], dt)
+        pos = np.arange(T)
+        bucket = t5_relative_bucket(pos[None, :] - pos[:, None], c["relative_attention_num_buckets"], c["relative_attention_max_distance"])
+        bias = rt(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"][bucket], dt).transpose(2, 0, 1)   # [H,T,T]
+        neg = F32(-3.3895313892515355e38) if dt == "bf16" else np.finfo(F32).min                                              # finfo(dtype).min
+        ext = (F32(1.0) - mask.astype(F32))[:, None, None, :] * neg
+        pb = rt(bias[None] + ext, dt)                                                                                          # [B,H,T,T]
+        for l in range(c["num_layers"]):
+            p = f"encoder.block.{l}.layer."
+            n = rmsnorm(h, sd[p + "0.layer_norm.weight"], eps, dt)
+            q = linear(n, sd[p + "0.SelfAttention.q.weight"], dt).reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+            k = linear(n, sd[p + "0.SelfAttention.k.weight"], dt).reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+            v = linear(n, sd[p + "0.SelfAttention.v.weight"], dt).reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+            s = rt(rt(np.einsum("bhid,bhjd->bhij", q.astype(F32), k.astype(F32)), dt) + pb, dt)                               # no 1/sqrt(d)
+            pr = rt(softmax_lastdim(s), dt)
+            a = rt(np.einsum("bhij,bhjd->bhid", pr, v.astype(F32)), dt).transpose(0, 2, 1, 3).reshape(B, T, H * dk)
+            h = rt(h + linear(a, sd[p + "0.SelfAttention.o.weight"], dt), dt)
+            n = rmsnorm(h, sd[p + "1.layer_norm.weight"], eps, dt)
+            g = rt(rt(gelu_tanh(linear(n, sd[p + "1.DenseReluDense.wi_0.weight"], dt)), dt) * linear(n, sd[p + "1.DenseReluDense.wi_1.weight"], dt), dt)
+            h = rt(h + linear(g, sd[p + "1.DenseReluDense.wo.weight"], dt), dt)
+        return rmsnorm(h, sd["encoder.final_layer_norm.weight"], eps, dt)

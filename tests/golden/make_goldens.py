@@ -361,6 +361,30 @@ def gold_gptb(out):
 
 PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff, videovq=gold_videovq)
 
+def gold_t5(out):
+    """transformers.T5EncoderModel (the class language/t5.py:60 loads) on CPU with the build's deterministic weights: fp32 and bf16,
+    12 tokens, one fully valid row and one padded to 5 valid tokens (padding='max_length' convention, language/t5.py:66-74)."""
+    from transformers import T5Config, T5EncoderModel
+    cfg = cases.TINY_T5
+    sd = detweights.t5_weights(cfg)
+    ids = cases.rng(71).integers(0, cfg["vocab_size"], size=(2, 12)).astype(np.int64)
+    mask = np.ones((2, 12), np.int64)
+    mask[1, 5:] = 0
+    ids[1, 5:] = 0
+    out["t5_ids"], out["t5_mask"] = ids, mask
+    for dt_name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = T5EncoderModel(T5Config(**cfg)).eval()
+        missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected and all(k.endswith("embed_tokens.weight") for k in missing), (missing, unexpected)
+        m = m.to(dtype)
+        with torch.no_grad():
+            y = m(input_ids=t(ids), attention_mask=t(mask))["last_hidden_state"]
+        out[f"t5_{dt_name}"] = y.float().numpy()
+
+
+PARTS["t5"] = gold_t5
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=",".join(PARTS))

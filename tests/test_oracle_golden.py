@@ -232,3 +232,18 @@ def test_encoders(golden):
     ref = gv["vae_tiled_moments"]
     assert mt.shape == ref.shape == (1, 16, 3, 6, 6)
     np.testing.assert_allclose(mt, ref, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_t5_encoder(golden, dt):
+    """Text-conditioning step (language/t5.py:60-81): oracle vs transformers.T5EncoderModel on the same weights / ids / padding mask."""
+    g = golden("t5")
+    cfg = cases.TINY_T5
+    y = O.T5Oracle(cfg, detweights.t5_weights(cfg), dt).encode(g["t5_ids"], g["t5_mask"])
+    ref = g[f"t5_{dt}"]
+    assert y.shape == ref.shape == (2, 12, cfg["d_model"])
+    valid = g["t5_mask"].astype(bool)                      # padded query rows are never consumed downstream (emb_masks zero them)
+    tol = 2e-4 if dt == "fp32" else 6e-2
+    assert np.abs(y - ref)[valid].max() < tol * max(1.0, np.abs(ref).max())
+    # bucket function against hand-checked values (bidirectional, 32 buckets, max distance 128)
+    assert O.t5_relative_bucket(np.array([0, 1, -1, 7, 8, -8, 127, 128, -500])).tolist() == [0, 17, 1, 23, 24, 8, 31, 31, 15]

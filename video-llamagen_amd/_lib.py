@@ -48,6 +48,11 @@ class VqvaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_hiddens", "embedding_dim", "n_codes", "n_res_layers", "n_head", "n_upsample", "dtype")]
 
 
+class T5Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d_model", "d_kv", "num_heads", "d_ff", "num_layers", "vocab_size", "relative_attention_num_buckets",
+                                         "relative_attention_max_distance", "gated_gelu", "dtype")] + [("layer_norm_epsilon", C.c_float)]
+
+
 # every symbol include/vlg.h declares
 SYMBOLS = [
     "vlg_last_error", "vlg_version",
@@ -60,6 +65,7 @@ SYMBOLS = [
     "vlg_vae_create", "vlg_vae_destroy", "vlg_vae_load_tensor", "vlg_vae_decode", "vlg_vae_out_shape",
     "vlg_vq_encode", "vlg_vae_encode",
     "vlg_vqvae_create", "vlg_vqvae_destroy", "vlg_vqvae_load_tensor", "vlg_vqvae_decode",
+    "vlg_t5_create", "vlg_t5_destroy", "vlg_t5_load_tensor", "vlg_t5_encode",
 ]
 
 _lib = None
