@@ -19,6 +19,7 @@ struct vlg_t5 {
   int dtype;
   size_t esz;
   std::map<std::string, Tensor> w;       // handle-dtype tensors by their transformers state-dict name (+ merged "...qkv", "...wi")
+  std::map<std::string, int> parts;      // merged tensors: bit mask of the parts loaded so far
   DevBuf bias_tab;                       // fp32 [num_buckets][H]
   DevBuf x, xn, qkv, att, g, ws, bias;   // activations [M, .], fp32 slabs, per-call bias [H][T][T]
   hipStream_t st = nullptr;
@@ -242,6 +243,7 @@ extern "C" int vlg_t5_load_tensor(vlg_t5_t* h, const char* name, const void* dat
   }
   std::string target = n;
   int64_t row_off = 0, rows = ndim > 0 ? shape[0] : 1;
+  int part = 0, nparts = 1;
   auto ends = [&](const char* suf) {
     const size_t L = strlen(suf);
     return n.size() >= L && n.compare(n.size() - L, L, suf) == 0;
@@ -250,30 +252,30 @@ extern "C" int vlg_t5_load_tensor(vlg_t5_t* h, const char* name, const void* dat
     if (ends(qn.first)) {
       target = n.substr(0, n.size() - strlen("q.weight")) + "qkv";
       row_off = qn.second * inner;
+      part = qn.second;
+      nparts = 3;
     }
   for (auto wn : {std::pair<const char*, int>{".DenseReluDense.wi_0.weight", 0}, {".DenseReluDense.wi_1.weight", 1}})
     if (ends(wn.first)) {
       target = n.substr(0, n.size() - strlen("wi_0.weight")) + "wi";
       row_off = wn.second * F;
+      part = wn.second;
+      nparts = 2;
     }
   auto it = h->w.find(target);
   if (it == h->w.end()) return VLG_OK;   // strict=False
   Tensor& t = it->second;
   const int64_t cols = t.shape.size() > 1 ? t.shape[1] : 1;
   const bool merged = target != n;
-  bool ok = merged ? (ndim == 2 && shape[1] == cols && rows == (target.back() == 'v' ? inner : F)) : ((int)t.shape.size() == ndim);
+  bool ok = merged ? (ndim == 2 && shape[1] == cols && rows == (nparts == 3 ? inner : F)) : ((int)t.shape.size() == ndim);
   if (!merged)
     for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == t.shape[i];
   VLG_CHECK(ok, VLG_ERR_BAD_SHAPE, "size mismatch for %s", name);
   (void)D;
   VLG_TRY(upload_convert((char*)t.buf.p + (size_t)row_off * cols * h->esz, h->dtype, data, src_dtype, src_on_device, numel, h->st));
-  if (!merged) {
-    t.loaded = true;
-  } else {   // loaded once all parts came in: count rows through a side counter in shape's spare slot
-    if (t.shape.size() == 2) t.shape.push_back(0);
-    t.shape[2] += rows;
-    t.loaded = t.shape[2] >= t.shape[0];
-  }
+  int& got = h->parts[target];
+  got |= 1 << part;
+  t.loaded = got == (1 << nparts) - 1;   // a merged tensor is complete once q, k, v (wi_0, wi_1) all came in
   if (consumed) *consumed = 1;
   return VLG_OK;
 }
