@@ -36,8 +36,14 @@ def test_sample_t2i_and_t2v(tmp_path):
     out = str(tmp_path / "t2i")
     sample_t2i.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="t2i", cls_token_num=120, precision="bf16", vq_model="VQ-16", vq_ckpt=None,
                         codebook_size=16384, codebook_embed_dim=8, image_size=256, downsample_size=16, cfg_scale=7.5, seed=0, top_k=1000,
-                        temperature=1.0, top_p=1.0, num_samples=2, out=out))
+                        temperature=1.0, top_p=1.0, num_samples=2, out=out, t5_layers=0))
     assert np.load(out + ".npy").shape == (2, 256, 256, 3)
+    # with the text encoder in the loop (one flan-t5-xl-shaped layer, random init): T5 -> left padding -> generate -> VQ decode
+    sample_t2i.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="t2i", cls_token_num=120, precision="bf16", vq_model="VQ-16", vq_ckpt=None,
+                        codebook_size=16384, codebook_embed_dim=8, image_size=256, downsample_size=16, cfg_scale=7.5, seed=0, top_k=1000,
+                        temperature=1.0, top_p=1.0, num_samples=2, out=out + "_t5", t5_layers=1))
+    img = np.load(out + "_t5.npy")
+    assert img.shape == (2, 256, 256, 3) and img.std() > 0
     out = str(tmp_path / "t2v")
     sample_t2v.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="t2v", cls_token_num=120, precision="bf16", vae_model="VAE-16", vae_ckpt=None,
                         vae_embed_dim=8, tile_overlap_factor=0.125, image_size=64, downsample_size=8, num_frames=5, t_downsample_size=4,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Text-conditional image sampling: counterpart of autoregressive/sample/sample_t2i.py:32-169 with synthetic T5-shaped
-embeddings in place of T5Embedder (language/t5.py needs network weights)."""
+embeddings, or (--t5-layers N) a random-init flan-t5-xl-shaped T5 encoder on synthetic token ids, in place of the pretrained T5Embedder
+(language/t5.py needs the network for weights and tokenizer)."""
 import argparse
 import os
 import sys
@@ -25,7 +26,25 @@ def main(args):
     gpt_model = V.GPT_models[args.gpt_model](block_size=latent_size ** 2, cls_token_num=args.cls_token_num,
                                              model_type=args.gpt_type).to(device=device, dtype=precision).eval()
     print("gpt model:", load_or_init(gpt_model, args.gpt_ckpt, 2))
-    c_indices, c_emb_masks = synthetic_text(args.num_samples, args.cls_token_num, 2048, args.seed, device)
+    if args.t5_layers > 0:
+        # sample_t2i.py:88-119 with the text encoder in the loop: T5Embedder -> [B,120,2048] embeddings + mask, LEFT-padded as the
+        # reference re-packs them (:105-119).  Random-init encoder and synthetic token ids (no tokenizer / weights without network).
+        t5 = V.T5EncoderModel(dict(V.t5_model.FLAN_T5_XL, num_layers=args.t5_layers)).to(device, precision).init_random_weights(seed=3)
+        g = torch.Generator().manual_seed(args.seed)
+        lens = torch.randint(8, args.cls_token_num + 1, (args.num_samples,), generator=g)
+        ids = torch.randint(1, 32128, (args.num_samples, args.cls_token_num), generator=g)
+        msk = (torch.arange(args.cls_token_num)[None, :] < lens[:, None]).long()
+        with Timer("text encoder"):
+            embs, emb_masks = V.T5Embedder(device, t5, model_max_length=args.cls_token_num).get_text_embeddings_from_ids(ids * msk, msk)
+        new_embs, new_masks = [], []
+        for e, mk in zip(embs.float(), emb_masks):                  # valid tokens to the right (sample_t2i.py:105-119)
+            n = int(mk.sum())
+            new_embs.append(torch.cat([e[n:], e[:n]]))
+            new_masks.append(torch.flip(mk, dims=[-1]))
+        c_emb_masks = torch.stack(new_masks).float()
+        c_indices = torch.stack(new_embs) * c_emb_masks[:, :, None]
+    else:
+        c_indices, c_emb_masks = synthetic_text(args.num_samples, args.cls_token_num, 2048, args.seed, device)
 
     def run(c, m):
         qzshape = [len(c), args.codebook_embed_dim, latent_size, latent_size]
@@ -58,6 +77,8 @@ if __name__ == "__main__":
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--top-k", type=int, default=1000)
     p.add_argument("--temperature", type=float, default=1.0)
+    p.add_argument("--t5-layers", type=int, default=0, help="> 0: run a (random-init) flan-t5-xl-shaped text encoder with this many layers "
+                   "on synthetic token ids instead of using synthetic embeddings")
     p.add_argument("--top-p", type=float, default=1.0)
     p.add_argument("--num-samples", type=int, default=4)
     p.add_argument("--out", type=str, default="sample_t2i")

@@ -72,6 +72,33 @@ class T5EncoderModel:
             raise RuntimeError("Unexpected key(s) in state_dict: " + ", ".join(unexpected))
         return [], unexpected
 
+    def init_random_weights(self, seed=0):
+        """Random initialisation on the device (stand-in for from_pretrained: the published weights need the network)."""
+        self._ensure_handle()
+        c = self.config
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        D, inner, F = c.d_model, c.num_heads * c.d_kv, c.d_ff
+
+        def put(name, shape, std):
+            t = torch.ones(shape, device=self._device) if std is None else torch.randn(shape, generator=g, device=self._device) * std
+            self.load_state_dict({name: t})
+
+        put("shared.weight", (c.vocab_size, D), 1.0)
+        put("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (c.relative_attention_num_buckets, c.num_heads), 0.5)
+        put("encoder.final_layer_norm.weight", (D,), None)
+        for l in range(c.num_layers):
+            p = "encoder.block.%d.layer." % l
+            put(p + "0.SelfAttention.q.weight", (inner, D), (D * c.d_kv) ** -0.5)
+            for n in ("k", "v"):
+                put(p + "0.SelfAttention.%s.weight" % n, (inner, D), D ** -0.5)
+            put(p + "0.SelfAttention.o.weight", (D, inner), inner ** -0.5)
+            put(p + "1.DenseReluDense.wi_0.weight", (F, D), D ** -0.5)
+            put(p + "1.DenseReluDense.wi_1.weight", (F, D), D ** -0.5)
+            put(p + "1.DenseReluDense.wo.weight", (D, F), F ** -0.5)
+            put(p + "0.layer_norm.weight", (D,), None)
+            put(p + "1.layer_norm.weight", (D,), None)
+        return self
+
     @torch.no_grad()
     def __call__(self, input_ids=None, attention_mask=None):
         self._ensure_handle()
