@@ -128,3 +128,43 @@ def test_continuous_engine_matches_generate():
         o = llm.generate(prompt_token_ids=[[207], [360], [387], [1000], [1000], [1000]], sampling_params=sp, use_tqdm=False)
         runs.append([x.outputs[0].token_ids for x in o])
     assert runs[0] == runs[1] and all(len(t) == 16 and min(t) >= 0 and max(t) < 16384 for t in runs[0]) and runs[0][0] == runs[0][3]
+
+
+def test_session_and_t5_error_paths():
+    """Loud failures instead of silent fallbacks: sessions on a text-conditioned model, stepping without a session, slot overrun,
+    T5 configurations / sequence lengths that are not built."""
+    import ctypes as C
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib as L
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    sp = L.SamplingParams(cfg_scale=1.0, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=0, seed=0)
+    t2i, _ = product_gpt(cases.TINY_T2I, torch.float32)
+    with pytest.raises(L.VlgError, match="class-conditional"):
+        L.check(L.lib().vlg_gpt_session_begin(t2i._handle, 2, 4, C.byref(sp)))
+    c2i, _ = product_gpt(cases.TINY_C2I, torch.float32)
+    rows = (C.c_int32 * 2)(1, -2)
+    with pytest.raises(L.VlgError, match="no open session"):
+        L.check(L.lib().vlg_gpt_session_step(c2i._handle, rows))
+    with pytest.raises(L.VlgError, match="RoPE table"):
+        L.check(L.lib().vlg_gpt_session_begin(c2i._handle, 2, 17, C.byref(sp)))
+    L.check(L.lib().vlg_gpt_session_begin(c2i._handle, 2, 3, C.byref(sp)))
+    L.check(L.lib().vlg_gpt_session_step(c2i._handle, rows))
+    cont = (C.c_int32 * 2)(-1, -2)
+    L.check(L.lib().vlg_gpt_session_step(c2i._handle, cont))
+    L.check(L.lib().vlg_gpt_session_step(c2i._handle, cont))
+    with pytest.raises(L.VlgError, match="max_new_tokens"):
+        L.check(L.lib().vlg_gpt_session_step(c2i._handle, cont))           # a 4th token in a 3-token slot
+    buf = (C.c_int32 * 3)()
+    L.check(L.lib().vlg_gpt_session_read(c2i._handle, 0, 3, buf))
+    assert list(buf) == V.generate(c2i, torch.tensor([1]), 3, sample_logits=False).cpu().tolist()[0]
+    with pytest.raises(L.VlgError):
+        L.check(L.lib().vlg_gpt_session_read(c2i._handle, 5, 1, buf))
+    L.check(L.lib().vlg_gpt_session_end(c2i._handle))
+    with pytest.raises(L.VlgError, match="gated-gelu"):
+        V.T5EncoderModel(dict(cases.TINY_T5, feed_forward_proj="relu"))
+    t5 = V.T5EncoderModel(cases.TINY_T5).to("cuda", torch.float32).init_random_weights(seed=1)
+    with pytest.raises(L.VlgError):
+        t5(input_ids=torch.zeros(1, 300, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        t5.load_state_dict({"decoder.block.0.layer.0.layer_norm.weight": torch.ones(64)})
