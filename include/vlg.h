@@ -121,6 +121,9 @@ int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
 /* event-timed attention launches of the last generate() with time_attn=1: total ms, total algorithmic KV bytes
  * (2 * Bp * D * (p+1) * elem per launch), number of launches                                                      */
 int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches);
+/* mean elapsed time (ms) of an EMPTY event pair recorded back to back on the same stream right after that run: what the
+ * bracket itself adds to every timed launch                                                                        */
+int vlg_gpt_attn_event_overhead(vlg_gpt_t* h, double* ms_per_pair);
 
 /* ------------------------------------------------------------------------------------------
  * Unit entry points (parity tests call the very kernels the handle uses)

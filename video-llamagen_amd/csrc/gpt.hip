@@ -71,6 +71,7 @@ struct vlg_gpt {
   bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
   std::vector<hipEvent_t> attn_ev;   // 2 per decode step
   double attn_ms_sum = 0, attn_bytes_sum = 0;
+  double attn_pair_overhead_ms = 0;   // mean elapsed time of an EMPTY event pair on the launch stream (calibration of the bracket itself)
   long long attn_launches = 0;
   double bytes_w = 0, bytes_kv = 0, bytes_other = 0;
 
@@ -372,6 +373,12 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
   }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
+}
+
+extern "C" int vlg_gpt_attn_event_overhead(vlg_gpt_t* h, double* ms_per_pair) {
+  VLG_CHECK(h && ms_per_pair, VLG_ERR_BAD_ARG, "vlg_gpt_attn_event_overhead: null argument");
+  *ms_per_pair = h->attn_pair_overhead_ms;
+  return VLG_OK;
 }
 
 extern "C" int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches) {
@@ -912,6 +919,22 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
         h->attn_bytes_sum += 2.0 * rs[0].Bp * D * (double)(Tc + i + 1) * h->esz;  // K and V rows 0..p of one layer, lane 0
       }
       h->attn_launches = steps;
+      // what the bracket itself costs: back-to-back event pairs with nothing between them, same stream, same session
+      {
+        const int ncal = std::min(64, steps);
+        for (int i = 0; i < ncal; ++i) {
+          VLG_HIP(hipEventRecord(h->attn_ev[2 * i], s0));
+          VLG_HIP(hipEventRecord(h->attn_ev[2 * i + 1], s0));
+        }
+        VLG_HIP(hipStreamSynchronize(s0));
+        double tot = 0;
+        for (int i = 0; i < ncal; ++i) {
+          float ms = 0.f;
+          VLG_HIP(hipEventElapsedTime(&ms, h->attn_ev[2 * i], h->attn_ev[2 * i + 1]));
+          tot += ms;
+        }
+        h->attn_pair_overhead_ms = ncal > 0 ? tot / ncal : 0.0;
+      }
     } else if (h->use_graph) {
       // one graph = one decode step of every lane, lanes on parallel branches (fork/join on lane 0's stream)
       hipGraph_t graph = nullptr;

@@ -261,6 +261,12 @@ class Transformer:
         L.check(L.lib().vlg_gpt_attn_timing(self._handle, C.byref(ms), C.byref(by), C.byref(n)))
         return ms.value, by.value, n.value
 
+    def attn_event_overhead_ms(self):
+        """mean elapsed ms of an empty event pair on the launch stream (calibration of the timing bracket)."""
+        ms = C.c_double()
+        L.check(L.lib().vlg_gpt_attn_event_overhead(self._handle, C.byref(ms)))
+        return ms.value
+
     def algorithmic_bytes(self):
         w, k, o = C.c_double(), C.c_double(), C.c_double()
         L.check(L.lib().vlg_gpt_last_algorithmic_bytes(self._handle, C.byref(w), C.byref(k), C.byref(o)))
