@@ -49,6 +49,12 @@ def test_sample_t2i_and_t2v(tmp_path):
                         vae_embed_dim=8, tile_overlap_factor=0.125, image_size=64, downsample_size=8, num_frames=5, t_downsample_size=4,
                         cfg_scale=1.0, seed=0, num_samples=2, out=out))
     vid = np.load(out + ".npy")
+    # the reference script's own model: hidden head + DiffLoss sampler (10 reverse steps here)
+    sample_t2v.main(_ns(gpt_model="GPT-B", gpt_ckpt=None, gpt_type="t2v", cls_token_num=120, precision="bf16", vae_model="VAE-16", vae_ckpt=None,
+                        vae_embed_dim=8, tile_overlap_factor=0.125, image_size=64, downsample_size=8, num_frames=5, t_downsample_size=4,
+                        cfg_scale=1.0, seed=0, num_samples=2, out=out + "_diff", head="hidden", num_sampling_steps=10, temperature=0.9))
+    assert np.load(out + "_diff.npy").shape == vid.shape
+    vid = np.load(out + ".npy")
     assert vid.shape == (2, 5, 64, 64, 3) and vid.dtype == np.uint8      # 2 latent frames -> 2T-1 = 3 -> 5 frames
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Text-to-video sampling: counterpart of autoregressive/sample/sample_t2v_1f_diff.py:61-257 (generate -> reshape
-[B,vae_t,h,w,C] -> permute -> vae.decode -> clamp -> uint8), adapter2 head, synthetic T5-shaped embeddings."""
+[B,vae_t,h,w,C] -> permute -> vae.decode -> clamp -> uint8), synthetic T5-shaped embeddings.  --head hidden is that script's model
+(gpt_video_diff + DiffLoss.sample, --num-sampling-steps reverse steps per token); --head adapter2 the MSE head of gpt_video.py."""
 import argparse
 import os
 import sys
@@ -27,14 +28,16 @@ def main(args):
     vae.tile_overlap_factor = args.tile_overlap_factor
     gpt_model = V.GPT_models[args.gpt_model](block_size=latent_size ** 2, cls_token_num=args.cls_token_num, model_type=args.gpt_type,
                                              vae_embed_dim=vae.config.embed_dim, num_frames=args.num_frames,
-                                             t_downsample_size=args.t_downsample_size).to(device=device, dtype=precision).eval()
+                                             t_downsample_size=args.t_downsample_size, head=getattr(args, "head", "adapter2"),
+                                             num_sampling_steps=getattr(args, "num_sampling_steps", 100)).to(device=device, dtype=precision).eval()
     print("gpt model:", load_or_init(gpt_model, args.gpt_ckpt, 2))
     cond, masks = synthetic_text(args.num_samples, args.cls_token_num, 2048, args.seed, device)
     vae_t = (args.num_frames - 1) // args.t_downsample_size + 1
 
     def run(c, m):
         with Timer("Full sampling"):
-            lat = V.generate_t2v(gpt_model, c, vae_t * latent_size ** 2, m, cfg_scale=args.cfg_scale)
+            lat = V.generate_t2v(gpt_model, c, vae_t * latent_size ** 2, m, cfg_scale=args.cfg_scale,
+                                 temperature=getattr(args, "temperature", 1.0), seed=args.seed)
         z = lat.view(-1, vae_t, latent_size, latent_size, vae.config.embed_dim).permute(0, 4, 1, 2, 3).contiguous()
         with Timer("decoder"):
             vids = [vae.decode(z[i:i + 4]) for i in range(0, z.shape[0], 4)]
@@ -69,6 +72,9 @@ if __name__ == "__main__":
     p.add_argument("--num_frames", type=int, default=17)
     p.add_argument("--t-downsample-size", type=int, default=4)
     p.add_argument("--cfg-scale", type=float, default=1.0)
+    p.add_argument("--head", type=str, choices=["adapter2", "hidden"], default="adapter2", help="hidden = gpt_video_diff + DiffLoss sampler")
+    p.add_argument("--num-sampling-steps", type=int, default=100, help="DiffLoss reverse steps per token (gpt_video_diff.py:78)")
+    p.add_argument("--temperature", type=float, default=1.0)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--num-samples", type=int, default=4)
     p.add_argument("--out", type=str, default="sample_t2v")
