@@ -6,10 +6,20 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one full pass of the hot path over one batch of synthetic conditions on every rank:
-prefill (120 text tokens) + 5119 KV-cached decode steps for `--batch` videos (5 x 32 x 32 latent tokens each,
-BASELINE config 4 / SURVEY.md §8d "C4 ds 8"), the CausalVideoVAE decode of those latents to 17 x 256 x 256
-frames, and (N > 1) the one RCCL all-gather of the results.  Batch shards are independent: per-GPU work is
-fixed as N grows ("weak").  Prints ONE JSON line on rank 0.
+prefill (120 text tokens) + 5119 KV-cached decode steps for the rank's videos (5 x 32 x 32 latent tokens each,
+BASELINE config 4 / SURVEY.md 8d "C4 ds 8"), the CausalVideoVAE decode of those latents to 17 x 256 x 256
+frames, and (N > 1) the one RCCL all-gather of the results.
+
+Scaling ("B 32 total, sharded 32/16/8/4 per GPU"): with N > 1 the default is `--scaling strong` - the GLOBAL batch
+stays `--batch` (32) and every rank takes batch / N videos; `--scaling weak` keeps `--batch` videos per GPU.  At N = 1 they coincide.
+
+Prints ONE JSON line on rank 0.  Besides the contract keys it carries
+  roofline        the dominant kernel (split-KV decode attention, HBM-bound), HIP-event timed inside one warm-up step
+  roofline_vae    the dominant decoder kernel (halo-tile implicit-GEMM conv, MFMA-bound), HIP-event timed in one decode
+  cpu_baseline    the numpy oracle on the host cores on a bounded sample of the same workload (sampling leg + VAE leg)
+  extra_configs   short driver-observed runs of BASELINE configs 2, 3, 5 and of the DiffLoss-head variant of config 4
+The extras run only while the process is inside its time budget (`--budget-s`, default 500 s from start, so that the default
+driver run stays well inside its 600 s limit); what was skipped is listed.
 """
 import argparse
 import json
@@ -17,23 +27,30 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+T_START = time.perf_counter()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_gpt(V, a, device):
+def elapsed():
+    return time.perf_counter() - T_START
+
+
+def build_gpt(V, a, device, head=None):
     m = V.GPT_models[a.gpt_model](block_size=a.latent ** 2, cls_token_num=120, model_type="t2v",
                                   vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4,
-                                  caption_dim=2048, head=a.head)
+                                  caption_dim=2048, head=head or a.head)
     m.to(device=device, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).eval()
     m.init_random_weights(seed=1234)
     return m
@@ -50,8 +67,8 @@ def synth_cond(B, device, seed):
 
 
 def cpu_baseline(a):
-    """The numpy oracle (a port, not the reference) on the host cores, on a bounded sample of the same workload:
-    GPT-XL t2v fp32, same shapes, batch `cb`, prefill + a few decode steps."""
+    """The numpy oracle (a port, not the reference) on the host cores, on a bounded sample of the same workload: GPT-XL t2v fp32,
+    same shapes, batch 4, prefill + 5 decode steps; then one latent frame of the CausalVideoVAE decoder at full width."""
     import threadpoolctl  # noqa: F401  (numpy BLAS thread count is reported)
     from oracle import cases, detweights
     from oracle import vlg_oracle as O
@@ -66,13 +83,69 @@ def cpu_baseline(a):
     t0 = time.time()
     O.generate_t2v(m, c, nsteps, mk)
     dt = time.time() - t0
+    del m, sd
     try:
         cores = threadpoolctl.threadpool_info()[0]["num_threads"]
     except Exception:
         cores = os.cpu_count()
-    return {"value": cb * nsteps / dt, "unit": "video tokens/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle, {a.gpt_model} t2v fp32, batch {cb}, prefill(120)+{nsteps - 1} decode steps "
-                      f"({cb * nsteps} tokens at positions 120..{120 + nsteps - 1}) in {dt:.1f}s"}
+    res = {"value": cb * nsteps / dt, "unit": "video tokens/s", "cores": int(cores), "kind": "port",
+           "sample": f"numpy oracle, {a.gpt_model} t2v fp32, batch {cb}, prefill(120)+{nsteps - 1} decode steps "
+                     f"({cb * nsteps} tokens at positions 120..{120 + nsteps - 1}) in {dt:.1f}s"}
+    # VAE leg: the decoder at its real channel widths (512/256/128) on ONE latent frame of 16 x 16 cells -> 1 x 128 x 128 pixels
+    # (a quarter of a 256-px frame: 0.37 TFLOP), so the whole baseline stays within ~30 s of CPU work
+    vcfg = dict(hidden_size=128, z_channels=4, embed_dim=a.vae_embed_dim, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2)
+    vsd = detweights.vae_weights(vcfg)
+    vo = O.VAEOracle(vsd, hidden_size=128, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2)
+    z = cases.rng(9).standard_normal((1, a.vae_embed_dim, 1, 16, 16), dtype=np.float32)
+    t0 = time.time()
+    y = vo.decode(z)
+    dv = time.time() - t0
+    res["vae"] = {"value": 0.25 / dv, "unit": "256x256-frame equivalents/s", "sample":
+                  f"numpy oracle, CausalVideoVAE decoder (constructor defaults, fp32), 1 latent frame 16x16 -> {tuple(y.shape)} in {dv:.1f}s "
+                  f"(0.37 TFLOP; a 17-frame 256x256 video is 19.95 TFLOP)"}
+    return res
+
+
+def run_extra_configs(V, device, budget_s):
+    """BASELINE configs 2, 3, 5 (one GPU's share) - sampling wall time of one generate() after one warm-up, random weights, bf16.
+    Each entry is skipped (and says so) once the process has used its time budget."""
+    from video_llamagen_amd.sample_common import synthetic_text
+    out, skipped = {}, []
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def c2i(tag, name, B, grid, cfg_scale, top_k, est_s):
+        if elapsed() + est_s > budget_s:
+            skipped.append(tag)
+            return
+        m = V.GPT_models[name](block_size=grid * grid, cls_token_num=1, model_type="c2i").to(device, torch.bfloat16).init_random_weights(seed=1)
+        cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(0)).to(device)
+        dt = timed(lambda: V.generate(m, cond, grid * grid, cfg_scale=cfg_scale, temperature=1.0, top_k=top_k, top_p=1.0, sample_logits=True, seed=7))
+        wb, kb, ob = m.algorithmic_bytes()
+        out[tag] = {"workload": f"{name} c2i {16 * grid}x{16 * grid} ({grid * grid} tokens), {B} images, cfg {cfg_scale}, top-k {top_k}, bf16, sampling only",
+                    "sampling_s": dt, "tokens_per_s": B * grid * grid / dt, "hbm_floor_s_at_8TBs": (wb + kb + ob) / 8e12}
+        del m
+
+    c2i("C2", "GPT-L", 8, 24, 4.0, 2000, 8)          # serve/sample_c2i.py:88-95, the README workload
+    if elapsed() + 12 <= budget_s:
+        m = V.GPT_models["GPT-XL"](block_size=1024, cls_token_num=120, model_type="t2i").to(device, torch.bfloat16).init_random_weights(seed=1)
+        cond, mask = synthetic_text(4, 120, 2048, 1, device)
+        dt = timed(lambda: V.generate(m, cond, 1024, mask, cfg_scale=7.5, temperature=1.0, top_k=1000, top_p=1.0, sample_logits=True, seed=7))
+        wb, kb, ob = m.algorithmic_bytes()
+        out["C3"] = {"workload": "GPT-XL t2i 512x512 (1024 tokens), 120 text tokens, 4 images, cfg 7.5, top-k 1000, bf16, sampling only (T5 features given)",
+                     "sampling_s": dt, "tokens_per_s": 4 * 1024 / dt, "hbm_floor_s_at_8TBs": (wb + kb + ob) / 8e12}
+        del m
+    else:
+        skipped.append("C3")
+    c2i("C5", "GPT-3B", 32, 24, 1.65, 0, 20)         # one GPU's 32 of the 256 images (gpt.py:445, GETTING_STARTED.md:53): 64 rows, head_dim 100
+    torch.cuda.empty_cache()
+    return out, skipped
 
 
 def main():
@@ -80,7 +153,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="videos per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="videos: the global batch under --scaling strong, per GPU under --scaling weak")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="auto = strong when N > 1 (SURVEY.md 8d: 32 videos in total, sharded over the GPUs)")
     ap.add_argument("--gpt-model", default="GPT-XL")
     ap.add_argument("--latent", type=int, default=32, help="latent grid (256 px / downsample 8)")
     ap.add_argument("--num-frames", type=int, default=17)
@@ -94,6 +169,9 @@ def main():
     ap.add_argument("--vae-chunk", type=int, default=4, help="videos per vae.decode call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of configs 2, 3, 5 and of the DiffLoss head")
+    ap.add_argument("--budget-s", type=float, default=500.0, help="extras start only while the process is younger than this")
+    ap.add_argument("--hidden-tokens", type=int, default=256, help="tokens of the short DiffLoss-head run")
     ap.add_argument("--lanes", type=int, default=0, help="batch lanes inside generate (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of HIP-graph replay")
     ap.add_argument("--attn-inlaunch", action="store_true", help="merge the split-KV partials inside the attention launch (slower)")
@@ -115,21 +193,38 @@ def main():
             dist.init_process_group(backend)
 
     import video_llamagen_amd as V
+    from video_llamagen_amd import _lib as L
+    from video_llamagen_amd.dist import shard_range
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if scaling == "strong":
+        lo, hi = shard_range(a.batch, rank, world)          # contiguous shard of the global batch (dist.py; ragged when N does not divide it)
+        B, global_batch = hi - lo, a.batch
+        cond_all, mask_all = synth_cond(a.batch, device, seed=1)
+        cond, mask = cond_all[lo:hi].contiguous(), mask_all[lo:hi].contiguous()
+        del cond_all, mask_all
+        if B == 0:
+            raise SystemExit("--batch %d leaves rank %d without work at %d GPUs" % (a.batch, rank, world))
+    else:
+        B, global_batch = a.batch, a.batch * world
+        cond, mask = synth_cond(B, device, seed=1 + rank)
     vae_t = (a.num_frames - 1) // 4 + 1
     N = a.new_tokens or vae_t * a.latent ** 2
     full = N == vae_t * a.latent ** 2
-    B = a.batch
     gpt = build_gpt(V, a, device)
     gpt.lanes = a.lanes
     gpt.use_graph = not a.no_graph
     gpt.attn_inlaunch = a.attn_inlaunch
-    cond, mask = synth_cond(B, device, seed=1 + rank)
     vae = None
     if not a.no_vae and full:
-        # CausalVAEModel constructor defaults with embed_dim = vae_embed_dim (SURVEY.md §8d; the only decoder topology
+        # CausalVAEModel constructor defaults with embed_dim = vae_embed_dim (SURVEY.md 8d; the only decoder topology
         # fully defined in the reference), random-initialised, bf16 as in sample_t2v_1f_diff.py:180
         vae = V.VAE_models["VAE-16"](embed_dim=a.vae_embed_dim).to(device, torch.bfloat16).init_random_weights(seed=3)
         vae.enable_tiling()
+    if world > 1 and scaling == "strong":
+        # ragged shards (N does not divide the batch) are padded to the largest shard for the gather
+        Bmax = shard_range(a.batch, 0, world)[1]
+    else:
+        Bmax = B
 
     def step():
         lat = V.generate_t2v(gpt, cond, N, mask, cfg_scale=a.cfg_scale)
@@ -142,20 +237,34 @@ def main():
                 frames.append(((v.clamp(-1, 1) + 1) * 127.5).to(torch.uint8))   # custom_to_video, :49-58
             out = torch.cat(frames, 0)
         if world > 1:
+            if out.shape[0] < Bmax:
+                out = torch.cat([out, out.new_zeros((Bmax - out.shape[0],) + tuple(out.shape[1:]))], 0)
             # concatenated form [world * B, ...]: accepted by RCCL and by gloo (the stacked form [world, B, ...] is RCCL-only)
             gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=device)
             dist.all_gather_into_tensor(gathered, out.contiguous())
             out = gathered
         return out
 
-    for _ in range(a.warmup):
-        step()
+    # ---- warm-up: W untimed steps.  On rank 0 the first of them is also the roofline measurement: the same step with HIP events
+    # (on the library's launch stream) around layer 0's attention kernel of every decode step, and around every halo conv launch
+    # of the first vae.decode call.  No extra generate is spent on it.
+    roof_done = False
+    for w in range(a.warmup):
+        if w == 0 and rank == 0 and not a.no_roofline:
+            gpt.time_attn = True
+            L.check(L.lib().vlg_conv_timing(1))
+            step()
+            torch.cuda.synchronize()
+            gpt.time_attn = False
+            L.check(L.lib().vlg_conv_timing(0))
+            roof_done = True
+        else:
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    t_gen = 0.0
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
@@ -168,27 +277,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    tokens = world * B * N * a.steps
+    tokens = global_batch * N * a.steps
     res = {
         "metric": "video tokens/sec (whole job) for GPT-XL t2v 17f@256 sampling + VAE decode",
         "value": tokens / dt, "unit": "video tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.gpt_model} t2v ({a.head} head), 120 text tokens + {N} latent tokens "
                                f"({vae_t}x{a.latent}x{a.latent}, vae_embed_dim {a.vae_embed_dim}), cfg {a.cfg_scale}, "
-                               f"{B} videos per GPU, {'CausalVideoVAE decode to 17x256x256 included' if vae is not None else 'VAE decode NOT included'}",
-                   "global_batch": world * B, "seq_len": 120 + N, "parallelism": f"batch-shard x{world}"},
-        "frames_per_s": (world * B * a.num_frames * a.steps / dt) if vae is not None else None,
+                               f"{global_batch} videos in total = {B} on this GPU, "
+                               f"{'CausalVideoVAE decode to 17x256x256 included' if vae is not None else 'VAE decode NOT included'}",
+                   "global_batch": global_batch, "seq_len": 120 + N, "parallelism": f"batch-shard x{world} ({scaling})"},
+        "frames_per_s": (global_batch * a.num_frames * a.steps / dt) if vae is not None else None,
         "tokens_per_s_per_gpu": tokens / dt / world,
     }
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel = split-KV decode attention (reads K,V rows 0..p of one layer).  Extra eager pass with HIP
-        # events on the library's launch stream around layer 0's attention kernel of every decode step.
-        gpt.time_attn = True
-        V.generate_t2v(gpt, cond, N, mask, cfg_scale=a.cfg_scale)
-        torch.cuda.synchronize()
-        gpt.time_attn = False
+        if not roof_done:           # --warmup 0: one extra instrumented step after the timed region
+            gpt.time_attn = True
+            L.check(L.lib().vlg_conv_timing(1))
+            step()
+            torch.cuda.synchronize()
+            gpt.time_attn = False
+            L.check(L.lib().vlg_conv_timing(0))
         ms, by, n = gpt.attn_timing()
         # An EMPTY event pair on the same stream already measures a few us, so the bracketed time over-states the kernel (rocprofv3's
         # per-dispatch duration is ~3 us shorter).  `achieved` keeps the bracketed (conservative) time; the overhead is reported beside it.
@@ -205,7 +316,15 @@ def main():
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": tsrc, "kernel": "attn_partial_kernel", "launches_timed": n,
                                "avg_launch_us": 1e3 * ms / n, "avg_algorithmic_bytes_per_launch": by / n,
-                               "empty_event_pair_us": 1e3 * ovh}
+                               "empty_event_pair_us": 1e3 * ovh, "measured_in": "warm-up step 1 (eager launches, same kernels)"}
+        cms, cfl, cn = C_double(), C_double(), C_int64()
+        L.check(L.lib().vlg_conv_timing_read(byref(cms), byref(cfl), byref(cn)))
+        if cn.value > 0 and cms.value > 0:
+            tf = cfl.value / (cms.value * 1e-3) / 1e12
+            res["roofline_vae"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                                   "traffic": None, "kernel": "conv_halo_kernel", "launches_timed": cn.value,
+                                   "avg_launch_us": 1e3 * cms.value / cn.value, "avg_flop_per_launch": cfl.value / cn.value,
+                                   "measured_in": f"the vae.decode calls of warm-up step 1 ({a.vae_chunk} videos per call), bf16 MFMA"}
         wb, kb, ob = gpt.algorithmic_bytes()
         res["algorithmic_bytes_per_step"] = {"weights": wb, "kv": kb, "other": ob}
     if world > 1:
@@ -215,11 +334,44 @@ def main():
             res["cpu_baseline"] = cpu_baseline(a)
         except Exception as e:  # reported, never fatal for the GPU numbers
             res["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_extras:
+        # ---- driver-observed short runs of the other configurations (bounded by the time budget) ----
+        try:
+            del vae
+            torch.cuda.empty_cache()
+            extras, skipped = {}, []
+            if elapsed() + 6 <= a.budget_s and a.head != "hidden":
+                gh = build_gpt(V, a, device, head="hidden")
+                nh = a.hidden_tokens
+                V.generate_t2v(gh, cond, min(nh, 8), mask)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                V.generate_t2v(gh, cond, nh, mask)
+                torch.cuda.synchronize()
+                dth = time.perf_counter() - t
+                extras["C4_diffloss_head"] = {"workload": f"{a.gpt_model} t2v, hidden head + DiffLoss sampler (100 DDPM steps per token, gpt_video_diff.py), "
+                                                          f"{B} videos, first {nh} of 5120 latent tokens (positions 120..{119 + nh}), bf16, sampling only",
+                                              "sampling_s": dth, "tokens_per_s": B * nh / dth, "ms_per_token_step": 1e3 * dth / nh}
+                del gh
+            else:
+                skipped.append("C4_diffloss_head")
+            del gpt
+            torch.cuda.empty_cache()
+            ex, sk = run_extra_configs(V, device, a.budget_s)
+            extras.update(ex)
+            skipped += sk
+            res["extra_configs"] = extras
+            res["extra_configs_skipped"] = skipped
+        except Exception as e:
+            res["extra_configs"] = {"error": repr(e)}
     if rank == 0:
+        res["wall_s_total"] = elapsed()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
+
+from ctypes import byref, c_double as C_double, c_int64 as C_int64  # noqa: E402
 
 if __name__ == "__main__":
     main()

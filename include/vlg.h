@@ -8,7 +8,10 @@
  * Conventions
  *  - every function returns VLG_OK (0) or a negative vlg_status; vlg_last_error() gives the text.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued
- *    asynchronously on it; the caller synchronises.
+ *    asynchronously on it; the caller synchronises.  vlg_gpt_generate runs on handle-owned streams forked from
+ *    and joined back into `stream` with events: it returns once the work is enqueued, and anything the caller
+ *    enqueues on `stream` afterwards is ordered behind it.  (Exceptions, documented at the function: the
+ *    unit entry points and the session calls, which wait for their step.)
  *  - pointers named d_* are DEVICE pointers owned by the caller; weights / KV caches / workspaces are
  *    owned by the handle.  One handle is used by one host thread at a time (the reference's model
  *    object owns its caches and is not re-entrant either, gpt.py:318-332).
@@ -118,6 +121,9 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "lanes" (0 = auto:
  * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
+/* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last
+ * call and replays it while shape, sampling parameters, options and buffer addresses are unchanged                           */
+int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count);
 /* event-timed attention launches of the last generate() with time_attn=1: total ms, total algorithmic KV bytes
  * (2 * Bp * D * (p+1) * elem per launch), number of launches                                                      */
 int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches);
@@ -176,6 +182,13 @@ int vlg_vq_encode(vlg_vq_t* h, const float* d_x, int32_t B, int32_t Hh, int32_t 
  * d_z fp32 [n, dim] rows, d_codebook fp32 [n_codes, dim] -> int32 [n] (no normalisation)              */
 int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim,
                         int32_t* d_idx, void* stream);
+/* Codebook.forward in eval mode, tokenizer_video/vqvae.py:161-209 (== CausalVideoVAE quant.py:42-96):
+ * d_z fp32 [B, dim, n_pos] (the reference's [b, c, t, h, w] with n_pos = t*h*w), d_codebook fp32 [n_codes, dim] ->
+ *   d_encodings        int32 [B, n_pos]        nearest code per position (first minimum)
+ *   d_embeddings_st    fp32  [B, dim, n_pos]   (E[idx] - z) + z, the straight-through output        (optional, with the next)
+ *   d_loss_perplexity  fp32  [2]               {0.25 * mse(z, E[idx]), exp(-sum p log(p + 1e-10))}                          */
+int vlg_codebook_forward(const float* d_z, const float* d_codebook, int32_t B, int32_t dim, int64_t n_pos, int32_t n_codes,
+                         int32_t* d_encodings, float* d_embeddings_st, float* d_loss_perplexity, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * tokenizer_video VQ-VAE decode   replaces VQVAE.decode tokenizer/tokenizer_video/vqvae.py:48-51 (+ Decoder :245-272,
@@ -219,6 +232,33 @@ int vlg_vae_out_shape(vlg_vae_t* h, int32_t t, int32_t hh, int32_t ww, int32_t* 
 /* CausalVAEModel.encode up to the posterior parameters, modeling_causalvae.py:382-392 (Encoder :26-148 -> quant_conv):
  * d_x fp32 [B,3,T,H,W] -> d_moments fp32 [B, 2*embed_dim, (T-1)/4+1, H/8, W/8] = [mean | logvar]                      */
 int vlg_vae_encode(vlg_vae_t* h, const float* d_x, int32_t B, int32_t T_, int32_t Hh, int32_t Ww, float* d_moments, void* stream);
+/* Spatial tile compositing of the tiled passes: CausalVAEModel.tiled_decode2d / tiled_encode2d with blend_v / blend_h
+ * (modeling_causalvae.py:424-443,491-570).  Tiles [planes, th, tw] fp32 (planes = B*C*T) are visited in raster order; the call
+ * cross-fades d_tile IN PLACE over its first min(above_h, th, extent) rows against the last rows of the finished tile above
+ * (d_above [planes, above_h, tw] or NULL) and then over its first min(left_w, tw, extent) columns against the last columns of the
+ * finished tile to its left (d_left [planes, th, left_w] or NULL), and copies rows < keep_h, columns < keep_w of the result to
+ * d_canvas [planes, canvas_h, canvas_w] at (y0, x0).                                                                        */
+/* Unit entry points of the decoder kernels (per-op parity): planar fp32 tensors in the reference's layouts,
+ * computed by the handle kernels in `dtype`.  They synchronise the stream and use process-wide scratch: tests and tools only.
+ *   vlg_causal_conv3d    CausalConv3d (modules/conv.py:76-130): x [B,Cin,T,H,W], w [Cout,Cin,kt,kh,kw], bias [Cout] or NULL;
+ *                        replicate-first-frame time pad, "same" zero pad in H/W; stride_hw 2 = SpatialDownsample2x's conv (zero pad
+ *                        (0,1) bottom/right, updownsample.py:63-93); nearest_up 1 = SpatialUpsample2x (nearest x2 on H,W first, :124-153)
+ *   vlg_group_norm       Normalize (GroupNorm 32 groups, normalize.py:14-17) [+ swish, ops.py:14-15]: x [B,C,P]
+ *   vlg_time_upsample2x  TimeUpsample2x (updownsample.py:182-194): x [B,C,T,HW] -> [B,C,2T-1,HW]                                     */
+int vlg_causal_conv3d(const float* d_x, const float* d_w, const float* d_bias, int32_t B, int32_t Cin, int32_t T_, int32_t H,
+                      int32_t W, int32_t Cout, int32_t kt, int32_t kh, int32_t kw, int32_t stride_hw, int32_t nearest_up,
+                      int32_t dtype, float* d_out, void* stream);
+int vlg_group_norm(const float* d_x, const float* d_gamma, const float* d_beta, int32_t B, int32_t C, int64_t P, float eps,
+                   int32_t swish, int32_t dtype, float* d_out, void* stream);
+int vlg_time_upsample2x(const float* d_x, int32_t B, int32_t C, int32_t T_, int64_t HW, int32_t dtype, float* d_out, void* stream);
+/* Measurement hook (bench.py's MFMA roofline entry): with enable = 1 every halo-tile implicit-GEMM convolution launch of the
+ * decoders (conv_halo_kernel, 97 % of the CausalVideoVAE decoder's FLOPs) is bracketed by HIP events on the stream it runs on;
+ * read() waits for them and returns total ms, total FLOPs (2 * outputs * taps * Cin * Cout) and the launch count since enable.  */
+int vlg_conv_timing(int32_t enable);
+int vlg_conv_timing_read(double* ms_sum, double* flop_sum, int64_t* launches);
+int vlg_tile_blend(float* d_tile, const float* d_above, const float* d_left, int64_t planes, int32_t th, int32_t tw,
+                   int32_t above_h, int32_t left_w, int32_t extent, float* d_canvas, int32_t canvas_h, int32_t canvas_w,
+                   int32_t y0, int32_t x0, int32_t keep_h, int32_t keep_w, void* stream);
 
 /* ---- T5 text encoder: the conditioning step in front of t2i / t2v (language/t5.py:60-81 -> transformers.T5EncoderModel) ------
  * State-dict names are transformers' ("shared.weight", "encoder.block.{i}.layer.0.SelfAttention.{q,k,v,o}.weight",

@@ -692,6 +692,21 @@ def video_codebook_argmin(z, E):
     return np.argmin(d, axis=1).reshape((B,) + z.shape[2:]).astype(np.int64), d
 
 
+def video_codebook_forward(z, E):
+    """Codebook.forward in eval mode (tokenizer_video/vqvae.py:161-209 == quant.py:42-96): z [B,C,T,H,W], E [n_codes,C] ->
+    dict(embeddings [B,C,T,H,W] straight-through, encodings [B,T,H,W], commitment_loss, perplexity)."""
+    z = np.asarray(z, F32)
+    E = np.asarray(E, F32)
+    enc, _ = video_codebook_argmin(z, E)
+    emb = np.moveaxis(E[enc], -1, 1)                                                    # F.embedding + shift_dim(-1, 1)
+    loss = F32(0.25) * np.mean((z - emb).astype(F32) ** 2, dtype=np.float64).astype(F32)    # 0.25 * F.mse_loss(z, embeddings)
+    st = ((emb - z).astype(F32) + z).astype(F32)                                        # (embeddings - z).detach() + z
+    counts = np.bincount(enc.reshape(-1), minlength=E.shape[0]).astype(F32)
+    p = (counts / F32(enc.size)).astype(F32)                                            # torch.mean(encode_onehot, dim=0)
+    perplexity = np.exp(-np.sum((p * np.log(p + F32(1e-10))).astype(F32), dtype=np.float64)).astype(F32)
+    return dict(embeddings=st, encodings=enc, commitment_loss=loss, perplexity=perplexity)
+
+
 # ----------------------------------------------------------------------------
 # CausalVideoVAE decoder  (CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py:151-262,394-404)
 # ----------------------------------------------------------------------------

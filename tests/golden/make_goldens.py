@@ -97,10 +97,19 @@ def gold_gpt(out):
             step = [0]
             orig_mn = torch.multinomial
 
+            margins, slacks = [], []
+
             def mn(probs, num_samples=1, **k):
                 q = t(noise[step[0]])
                 step[0] += 1
-                return torch.argmax(probs / q, dim=-1, keepdim=True)
+                sc = (probs / q)
+                top2 = torch.topk(sc, 2, dim=-1).values
+                # how decided the draw was: log(best / runner-up) of p/q, and how many kept tokens rank below the drawn one in p
+                # (0 = it is the last token the top-k / top-p filter kept)
+                margins.append(torch.log(top2[:, 0] / top2[:, 1].clamp_min(1e-38)).numpy())
+                win = torch.argmax(sc, dim=-1, keepdim=True)
+                slacks.append(((probs > 0) & (probs < probs.gather(1, win))).sum(-1).numpy())
+                return win
 
             torch.multinomial = mn
             try:
@@ -108,6 +117,8 @@ def gold_gpt(out):
             finally:
                 torch.multinomial = orig_mn
             out[f"{tag}_{dt_name}_sample_ids"] = ids
+            out[f"{tag}_{dt_name}_sample_margin"] = np.stack(margins, 0).astype(np.float32)      # [N, B]
+            out[f"{tag}_{dt_name}_sample_slack"] = np.stack(slacks, 0).astype(np.int32)
             out[f"{tag}_{dt_name}_sample_logits0"] = lg[0].astype(np.float32)
 
 
@@ -150,6 +161,17 @@ def build_ref_vq(vqmod, sd):
     return m.eval()
 
 
+def vq_gap(quantize, z):
+    """Runner-up minus best distance of VectorQuantizer.forward's argmin (vq_model.py:215-233), from the module's own tensors with the
+    module's own expression: how decided each nearest-neighbour choice of the reference was."""
+    F = torch.nn.functional
+    zf = F.normalize(torch.einsum('b c h w -> b h w c', z).contiguous().view(-1, quantize.e_dim), p=2, dim=-1)
+    emb = F.normalize(quantize.embedding.weight, p=2, dim=-1)
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1) - 2 * torch.einsum('bd,dn->bn', zf, torch.einsum('n d -> d n', emb))
+    two = torch.topk(d, 2, dim=1, largest=False).values
+    return (two[:, 1] - two[:, 0]).numpy().astype(np.float32)
+
+
 def gold_vq(out):
     vqmod = ref_harness.load_vq()
     sd = detweights.vq_weights()
@@ -179,10 +201,12 @@ def gold_vq(out):
     out["vq_encode_z"] = hq.numpy()
     _, _, (_, _, eidx) = m.quantize(hq)
     out["vq_encode_idx"] = eidx.numpy()
+    out["vq_encode_gap"] = vq_gap(m.quantize, hq)
     # argmin incl. engineered ties (two identical codebook rows -> first index wins)
     z = cases.rng(22).standard_normal((2, 8, 6, 6), dtype=np.float32)
     _, _, (_, _, idx) = m.quantize(t(z))
     out["vq_argmin"] = idx.numpy()
+    out["vq_argmin_gap"] = vq_gap(m.quantize, t(z))
     m2 = build_ref_vq(vqmod, sd)
     w = m2.quantize.embedding.weight.data
     w[777] = w[5]
@@ -240,6 +264,92 @@ def gold_vae(out):
     st.tile_sample_min_size, st.tile_latent_min_size, st.tile_sample_min_size_t, st.tile_overlap_factor = 32, 4, 5, 0.25
     xt = cases.rng(37).standard_normal((1, 3, 9, 48, 48), dtype=np.float32)
     out["vae_tiled_moments"] = st.tiled_encode(t(xt)).numpy()
+
+
+def gold_vaeunits(out):
+    """Per-op I/O of the CausalVideoVAE building blocks from the reference's own modules, plus one full-width
+    single-frame decode (constructor defaults, 512/256/128 channels, [1,8,1,32,32] -> [1,3,1,256,256]) as statistics + crops."""
+    Decoder, mods = ref_harness.load_vae_decoder_cls()
+    import importlib
+    rb = importlib.import_module("causalvideovae.model.modules.resnet_block")
+    r = cases.rng
+
+    def w(seed, shape, std):
+        return (r(seed).standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    # CausalConv3d k3 (conv.py:76-130)
+    cc = mods.CausalConv3d(32, 64, 3, padding=1)
+    cc.load_state_dict({"conv.weight": t(w(82, (64, 32, 3, 3, 3), 0.05)), "conv.bias": t(w(83, (64,), 0.1))})
+    out["unit_conv_k3"] = cc(t(w(81, (1, 32, 3, 6, 6), 1.0))).numpy()
+    # SpatialDownsample2x: zero pad (0,1) + CausalConv3d (1,3,3) stride (1,2,2) (updownsample.py:63-93)
+    dn = mods.SpatialDownsample2x(32, 64)
+    dn.load_state_dict({"conv.conv.weight": t(w(85, (64, 32, 1, 3, 3), 0.08)), "conv.conv.bias": t(w(86, (64,), 0.1))})
+    out["unit_down"] = dn(t(w(84, (1, 32, 3, 8, 8), 1.0))).numpy()
+    # SpatialUpsample2x: nearest x2 + CausalConv3d (1,3,3) (updownsample.py:124-153)
+    up = mods.SpatialUpsample2x(32, 64)
+    up.load_state_dict({"conv.conv.weight": t(w(88, (64, 32, 1, 3, 3), 0.08)), "conv.conv.bias": t(w(89, (64,), 0.1))})
+    out["unit_up"] = up(t(w(87, (1, 32, 2, 4, 4), 1.0))).numpy()
+    # Normalize + swish (normalize.py:14-17, ops.py:14-15)
+    gn = mods.Normalize(64)
+    gn.load_state_dict({"weight": t(1 + w(91, (64,), 0.1)), "bias": t(w(92, (64,), 0.05))})
+    xg = t(w(90, (2, 64, 3, 4, 4), 1.5))
+    out["unit_gn"] = gn(xg).numpy()
+    out["unit_gn_swish"] = mods.nonlinearity(gn(xg)).numpy() if hasattr(mods, "nonlinearity") else (gn(xg) * torch.sigmoid(gn(xg))).numpy()
+    # ResnetBlock3D 32 -> 64 with the 1x1x1 shortcut (resnet_block.py:140-172)
+    res = rb.ResnetBlock3D(in_channels=32, out_channels=64, dropout=0.0).eval()
+    res.load_state_dict({"norm1.weight": t(1 + w(94, (32,), 0.1)), "norm1.bias": t(w(95, (32,), 0.05)),
+                         "conv1.conv.weight": t(w(96, (64, 32, 3, 3, 3), 0.04)), "conv1.conv.bias": t(w(97, (64,), 0.05)),
+                         "norm2.weight": t(1 + w(98, (64,), 0.1)), "norm2.bias": t(w(99, (64,), 0.05)),
+                         "conv2.conv.weight": t(w(100, (64, 64, 3, 3, 3), 0.03)), "conv2.conv.bias": t(w(101, (64,), 0.05)),
+                         "nin_shortcut.conv.weight": t(w(102, (64, 32, 1, 1, 1), 0.2)), "nin_shortcut.conv.bias": t(w(103, (64,), 0.05))})
+    out["unit_res"] = res(t(w(93, (1, 32, 3, 4, 4), 1.0))).numpy()
+    # full-width decoder, one frame
+    cfg = dict(hidden_size=128, z_channels=4, embed_dim=8, hidden_size_mult=(1, 2, 4, 4), num_res_blocks=2)
+    sd = detweights.vae_weights(cfg)
+    dec = Decoder(z_channels=4, hidden_size=128, hidden_size_mult=(1, 2, 4, 4), attn_resolutions=[], conv_in="CausalConv3d",
+                  conv_out="CausalConv3d", attention="AttnBlock3D", resnet_blocks=("ResnetBlock3D",) * 4,
+                  spatial_upsample=("", "SpatialUpsample2x", "SpatialUpsample2x", "SpatialUpsample2x"),
+                  temporal_upsample=("", "", "TimeUpsample2x", "TimeUpsample2x"), mid_resnet="ResnetBlock3D", dropout=0.0, resolution=256,
+                  num_res_blocks=2).eval()
+    dec.load_state_dict({k[len("decoder."):]: t(v) for k, v in sd.items() if k.startswith("decoder.")})
+    pq = mods.CausalConv3d(8, 4, 1)
+    pq.load_state_dict({"conv.weight": t(sd["post_quant_conv.conv.weight"]), "conv.bias": t(sd["post_quant_conv.conv.bias"])})
+    z = cases.rng(38).standard_normal((1, 8, 1, 32, 32), dtype=np.float32)
+    y = dec(pq(t(z))).numpy()
+    assert y.shape == (1, 3, 1, 256, 256)
+    out["full1f_stats"] = np.array([y.astype(np.float64).sum(), np.abs(y).astype(np.float64).sum(), y.min(), y.max()], np.float64)
+    out["full1f_crop"] = y[0, :, 0, 100:132, 100:132].copy()
+    out["full1f_grid"] = y[0, :, 0, ::8, ::8].copy()
+
+
+def gold_codebook(out):
+    """Codebook.forward in eval mode from the reference's own class (CausalVideoVAE/causalvideovae/model/modules/quant.py:8-99, the
+    byte-identical sibling of tokenizer_video/vqvae.py:130-213): default size 2048 x 256 on a [2,256,2,4,4] latent."""
+    ref_harness.load_vae_modules()
+    import importlib
+    quant = importlib.import_module("causalvideovae.model.modules.quant")
+    r = cases.rng(41)
+    E = r.standard_normal((2048, 256), dtype=np.float32)
+    z = r.standard_normal((2, 256, 2, 4, 4), dtype=np.float32)
+    cb = quant.Codebook(2048, 256).eval()
+    cb.embeddings.data.copy_(t(E))
+    cb._need_init = False
+    res = cb(t(z))
+    out["cb_encodings"] = res["encodings"].numpy()
+    out["cb_embeddings"] = res["embeddings"].numpy()
+    out["cb_commitment_loss"] = np.float32(res["commitment_loss"].item())
+    out["cb_perplexity"] = np.float32(res["perplexity"].item())
+    flat = t(z).permute(0, 2, 3, 4, 1).flatten(end_dim=-2)
+    d = (flat ** 2).sum(dim=1, keepdim=True) - 2 * flat @ cb.embeddings.t() + (cb.embeddings.t() ** 2).sum(dim=0, keepdim=True)
+    two = torch.topk(d, 2, dim=1, largest=False).values
+    out["cb_gap"] = (two[:, 1] - two[:, 0]).numpy().astype(np.float32)
+    # a latent made of codebook rows plus small noise: every position has a clear winner, many codes unused (perplexity << n_codes)
+    ids = r.integers(0, 64, size=(1, 3, 4, 4))
+    z2 = (np.moveaxis(E[ids], -1, 1) + 0.01 * r.standard_normal((1, 256, 3, 4, 4), dtype=np.float32)).astype(np.float32)
+    res2 = cb(t(z2))
+    assert (res2["encodings"].numpy() == ids).all()
+    out["cb2_commitment_loss"] = np.float32(res2["commitment_loss"].item())
+    out["cb2_perplexity"] = np.float32(res2["perplexity"].item())
 
 
 def gold_t2v(out):
@@ -359,7 +469,8 @@ def gold_gptb(out):
     out["gptb_top1"] = srt[:, -1].astype(np.float32)
 
 
-PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff, videovq=gold_videovq)
+PARTS = dict(rope=gold_rope, gpt=gold_gpt, sampler=gold_sampler, vq=gold_vq, vae=gold_vae, t2v=gold_t2v, gptb=gold_gptb, t2vdiff=gold_t2vdiff, videovq=gold_videovq,
+             vaeunits=gold_vaeunits, codebook=gold_codebook)
 
 def gold_t5(out):
     """transformers.T5EncoderModel (the class language/t5.py:60 loads) on CPU with the build's deterministic weights: fp32 and bf16,

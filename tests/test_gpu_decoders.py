@@ -53,7 +53,10 @@ def test_vq_argmin(golden):
     m, sd = _vq(torch.bfloat16)
     z = cases.rng(22).standard_normal((2, 8, 6, 6), dtype=np.float32)
     idx = m.quantize_indices(torch.from_numpy(z)).cpu().numpy()
-    assert (idx == g["vq_argmin"]).mean() > 0.98      # near-ties may flip (reduction order), exact ties may not:
+    # bit-exact wherever the reference's own runner-up distance is further away than fp32 reduction noise (distances of unit vectors
+    # lie in [0, 4]: 1e-5 is ~40 ulp); the golden's smallest gap is 9e-4, so here that is every position
+    decided = g["vq_argmin_gap"] > 1e-5
+    assert decided.all() and (idx == g["vq_argmin"])[decided].all()
     import video_llamagen_amd as V
     m2 = V.VQ_models["VQ-16"]().to("cuda").eval()
     E = sd["quantize.embedding.weight"].copy()
@@ -68,7 +71,7 @@ def test_vq_argmin(golden):
     zq = En[ids].reshape(4, 24, 24, 8).transpose(0, 3, 1, 2).copy()
     back = m.quantize_indices(torch.from_numpy(zq)).cpu().numpy()
     d_self = ((En[back] - En[ids]) ** 2).sum(-1)
-    assert (back == ids).mean() > 0.999 and d_self.max() < 1e-6
+    assert ((back == ids) | (d_self < 1e-6)).all() and (back == ids).mean() > 0.999      # duplicates of a row are equally near
 
 
 def test_video_codebook_argmin():
@@ -186,7 +189,14 @@ def test_vq_encode_and_round_trip(golden):
     _, _, (_, _, idx) = m.encode(torch.from_numpy(ximg))
     z = to_np(m.last_z)
     assert np.abs(z - g["vq_encode_z"]).max() < 2e-3 * np.abs(g["vq_encode_z"]).max()
-    assert (idx.cpu().numpy() == g["vq_encode_idx"]).mean() > 0.9       # near-ties of the 16384-way argmin may flip
+    # The encoder output differs from the reference's by fp32 conv summation order (dz); on unit vectors a perturbation dz of the query
+    # moves the difference of two squared distances by at most 4 |dz|: indices must agree wherever the reference's gap exceeds that.
+    zr = g["vq_encode_z"]
+    unit = lambda a: a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+    dz = np.linalg.norm(unit(z.transpose(0, 2, 3, 1).reshape(-1, 8)) - unit(zr.transpose(0, 2, 3, 1).reshape(-1, 8)), axis=1)
+    decided = g["vq_encode_gap"] > 4 * dz + 1e-5
+    same = idx.cpu().numpy() == g["vq_encode_idx"]
+    assert same[decided].all() and decided.mean() > 0.8, (same.mean(), decided.mean())
     # pipeline property at a full-size image: encode(decode_code(c)) has the right shape / index range
     code = cases.rng(25).integers(0, 16384, size=(1, 256)).astype(np.int64)
     img = m.decode_code(torch.from_numpy(code), [1, 8, 16, 16])

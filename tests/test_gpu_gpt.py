@@ -171,6 +171,23 @@ def test_sampler_cfg_and_philox(L):
         assert all(o[b] in top5[b] for b in range(2 * B))
 
 
+def _assert_sampled_ids(ids, ref_ids, margin, slack, eps=2e-3):
+    """Sampled ids under shared Exp(1) noise (argmax p/q): every sample must follow the reference's trajectory token for token until
+    a draw the reference itself decided by less than eps (log(best / runner-up) of p/q; fp32 logits agree to ~3e-4, so p/q ratios
+    to ~1e-3) or whose winner is the last token its top-k / top-p filter kept (slack 0); after such a draw the sequences may
+    differ (the token feeds back).  ids, ref_ids [B, N]; margin, slack [N, B]."""
+    B, N = ref_ids.shape
+    forks = 0
+    for b in range(B):
+        same = ids[b] == ref_ids[b]
+        if same.all():
+            continue
+        i = int(np.argmin(same))
+        assert margin[i, b] < eps or slack[i, b] == 0, (b, i, margin[i, b], slack[i, b])
+        forks += 1
+    assert forks <= max(1, B // 3), forks
+
+
 def _inputs(cfg, B=3):
     if cfg["model_type"] == "c2i":
         return torch.from_numpy(cases.class_ids(B, cfg["num_classes"])), None
@@ -211,7 +228,7 @@ def test_generate_vs_reference_golden(golden, tag, cfg, dt, graph):
     ids = V.generate(m, cond, N, masks, cfg_scale=3.0, temperature=0.9, top_k=50, top_p=0.95, sample_logits=True, noise=noise)
     ref_ids = g[f"{tag}_{dt}_sample_ids"]
     if dt == "fp32":
-        assert (ids.cpu().numpy() == ref_ids).mean() > 0.98
+        _assert_sampled_ids(ids.cpu().numpy(), ref_ids, g[f"{tag}_{dt}_sample_margin"], g[f"{tag}_{dt}_sample_slack"])
     else:
         assert (ids.cpu().numpy()[:, 0] == ref_ids[:, 0]).all()
 
@@ -278,8 +295,8 @@ def test_t2v_adapter2(golden, dt):
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_unfused_qkv_path_matches_fused(golden, dt):
-    """decode runs RoPE + KV append inside the attention kernel by default; the separate qkv_rope_scatter kernel (always
-    used by prefill) must give the same tokens when used for decode too."""
+    """RoPE + KV append can run inside the attention kernel (option fuse_qkv, off by default: the QKV GEMM's epilogue does it); the
+    two placements must give the same tokens."""
     import video_llamagen_amd as V
     cfg = cases.TINY_HD100 if dt == "fp32" else cases.TINY_C2I
     m, _ = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16)
@@ -328,7 +345,7 @@ def test_batch_lanes_do_not_change_results(golden, lanes):
     np.testing.assert_allclose(to_np(tr), g["t2i_fp32_cfg_logits"], atol=3e-4, rtol=1e-4)
     noise = torch.from_numpy(cases.exp_noise((16, 3, cfg["vocab_size"]), seed=7))
     ids = V.generate(m, cond, 16, masks, cfg_scale=3.0, temperature=0.9, top_k=50, top_p=0.95, sample_logits=True, noise=noise)
-    assert (ids.cpu().numpy() == g["t2i_fp32_sample_ids"]).mean() > 0.98
+    _assert_sampled_ids(ids.cpu().numpy(), g["t2i_fp32_sample_ids"], g["t2i_fp32_sample_margin"], g["t2i_fp32_sample_slack"])
     # Philox noise is keyed by the global sample id: identical draws for any lane split
     m.lanes = 1
     a = V.generate(m, cond, 16, masks, temperature=1.0, top_k=20, sample_logits=True, seed=5).cpu().numpy()
@@ -511,3 +528,31 @@ def test_every_model_width_fused_vs_slab_paths(name):
     assert torch.isfinite(tr_f).all() and scale > 0
     assert (tr_f[0] - tr_s[0]).abs().max().item() < 4e-2 * scale        # step 0 = prefill: identical inputs on both paths
     assert (tr_f[1] - tr_s[1]).abs().max().item() < 6e-2 * scale or not torch.equal(ids_f[:, 0], ids_s[:, 0])
+
+
+def test_generate_is_stream_ordered_and_reuses_its_graph():
+    """include/vlg.h: vlg_gpt_generate enqueues its work (on handle-owned streams forked from and joined into the caller's stream)
+    and returns; later work on the caller's stream is ordered behind it; the instantiated decode graph is kept and replayed while
+    shapes, parameters and buffers are unchanged."""
+    import video_llamagen_amd as V
+    m = V.GPT_models["GPT-B"](block_size=256, cls_token_num=1, model_type="c2i").to("cuda", torch.bfloat16).init_random_weights(seed=2)
+    c = torch.tensor([207, 360, 387, 974, 88, 979, 417, 279], device="cuda")
+    kw = dict(cfg_scale=4.0, temperature=1.0, top_k=2000, top_p=1.0, seed=3)
+    ref = V.generate(m, c, 256, **kw)
+    torch.cuda.synchronize()
+    n0 = m.graphs_built()
+    assert n0 >= 1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ids = V.generate(m, c, 256, **kw)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        pending = not ev.query()          # 255 graph replays of a 12-layer step take ~0.1 s; enqueuing them takes milliseconds
+        follow = ids.clone()              # enqueued behind generate() on the same stream: must see the finished ids
+    side.synchronize()
+    assert torch.equal(follow, ref) and torch.equal(ids, ref)
+    assert pending, "vlg_gpt_generate waited for the GPU"
+    assert m.graphs_built() == n0, "the decode graph was rebuilt for an identical call"
+    ids2 = V.generate(m, c, 128, **kw)    # another length: new graph, same tokens as the prefix (same noise stream per step)
+    assert m.graphs_built() == n0 + 1 and ids2.shape == (8, 128)
+    assert torch.equal(V.generate(m, c, 256, **kw), ref)

@@ -136,6 +136,38 @@ def test_continuous_engine_matches_generate():
     assert runs[0] == runs[1] and all(len(t) == 16 and min(t) >= 0 and max(t) < 16384 for t in runs[0]) and runs[0][0] == runs[0][3]
 
 
+def test_session_engines_vs_reference_golden(golden):
+    """The request front-ends against ids produced by the REFERENCE's generate() (tests/golden/gpt.npz, TINY_C2I, fp32 greedy): the
+    wave engine, the iteration-level engine with all requests started together, and the iteration-level engine with fewer slots
+    than requests (the third request starts in a freed slot, mid-flight of nothing else - its KV slot is reused).  With and without
+    classifier-free guidance (scale 2.5, cfg_interval 6 as in the golden run)."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    g = golden("gpt")
+    cfg = cases.TINY_C2I
+    m, _ = product_gpt(cfg, torch.float32)
+    labels = [int(c) for c in cases.class_ids(3, cfg["num_classes"])]
+    N = cfg["block_size"]
+    sp = V.SamplingParams(temperature=0.0, max_tokens=N)
+    null = cfg["num_classes"]
+
+    def run(engine, with_null):
+        for i, c in enumerate(labels + ([null] * 3 if with_null else [])):
+            engine.add_request(str(i), None, sp, [c])
+        outs = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+        return np.array([outs[i] for i in range(3)])
+
+    for slots in (3, 2):
+        assert (run(V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=slots), False) == g["c2i_fp32_greedy_ids"]).all(), slots
+        assert (run(V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=2 * slots), True) == g["c2i_fp32_cfg_ids"]).all(), slots
+    assert (run(V.LLMEngine(m, cfg_scale=1.0, max_num_seqs=3), False) == g["c2i_fp32_greedy_ids"]).all()
+    assert (run(V.LLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=6), True) == g["c2i_fp32_cfg_ids"]).all()
+
+
 def test_session_and_t5_error_paths():
     """Loud failures instead of silent fallbacks: sessions on a text-conditioned model, stepping without a session, slot overrun,
     T5 configurations / sequence lengths that are not built."""

@@ -247,3 +247,49 @@ def test_t5_encoder(golden, dt):
     assert np.abs(y - ref)[valid].max() < tol * max(1.0, np.abs(ref).max())
     # bucket function against hand-checked values (bidirectional, 32 buckets, max distance 128)
     assert O.t5_relative_bucket(np.array([0, 1, -1, 7, 8, -8, 127, 128, -500])).tolist() == [0, 17, 1, 23, 24, 8, 31, 31, 15]
+
+
+def test_vae_unit_ops_and_full_frame(golden):
+    """Per-op goldens from the reference's own CausalConv3d / SpatialDownsample2x / SpatialUpsample2x / Normalize / ResnetBlock3D
+    modules (tests/golden/vaeunits.npz) against the oracle's primitives; full-width one-frame decode statistics against the
+    oracle's decoder."""
+    g = golden("vaeunits")
+    u = cases.vae_unit_cases()
+
+    def close(a, ref, tol=2e-5):
+        assert a.shape == ref.shape and np.abs(a - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+    c = u["conv_k3"]
+    close(O.causal_conv3d(c["x"], c["w"], c["b"], 1), g["unit_conv_k3"])
+    c = u["down"]
+    close(O.conv_nd_general(c["x"], c["w"], c["b"], (1, 2, 2), ((0, 0), (0, 1), (0, 1)), causal_t=True), g["unit_down"])
+    c = u["up"]
+    close(O.causal_conv3d(O.nearest_up2(c["x"]), c["w"], c["b"], 1), g["unit_up"])
+    c = u["gn"]
+    close(O.group_norm(c["x"], c["g"], c["b"]), g["unit_gn"])
+    close(O.swish(O.group_norm(c["x"], c["g"], c["b"])), g["unit_gn_swish"])
+    c = u["res"]
+    h = O.causal_conv3d(O.swish(O.group_norm(c["x"], c["g1"], c["b1"])), c["w1"], c["c1"], 1)
+    h = O.causal_conv3d(O.swish(O.group_norm(h, c["g2"], c["b2"])), c["w2"], c["c2"], 1)
+    close(O.causal_conv3d(c["x"], c["ws"], c["cs"], 0) + h, g["unit_res"])
+
+
+def test_codebook_forward(golden):
+    """Codebook.forward (eval) of the reference's own class (tests/golden/codebook.npz): indices, straight-through embeddings,
+    commitment loss, perplexity."""
+    g = golden("codebook")
+    r = cases.rng(41)
+    E = r.standard_normal((2048, 256), dtype=np.float32)
+    z = r.standard_normal((2, 256, 2, 4, 4), dtype=np.float32)
+    res = O.video_codebook_forward(z, E)
+    assert g["cb_gap"].min() > 1e-2                       # every choice of the reference is decided far beyond fp32 summation noise
+    assert (res["encodings"] == g["cb_encodings"]).all()
+    np.testing.assert_array_equal(res["embeddings"], g["cb_embeddings"])
+    np.testing.assert_allclose(res["commitment_loss"], g["cb_commitment_loss"], rtol=2e-6)
+    np.testing.assert_allclose(res["perplexity"], g["cb_perplexity"], rtol=2e-5)
+    ids = r.integers(0, 64, size=(1, 3, 4, 4))
+    z2 = (np.moveaxis(E[ids], -1, 1) + 0.01 * r.standard_normal((1, 256, 3, 4, 4), dtype=np.float32)).astype(np.float32)
+    res2 = O.video_codebook_forward(z2, E)
+    assert (res2["encodings"] == ids).all()
+    np.testing.assert_allclose(res2["commitment_loss"], g["cb2_commitment_loss"], rtol=2e-5)
+    np.testing.assert_allclose(res2["perplexity"], g["cb2_perplexity"], rtol=2e-5)

@@ -57,13 +57,13 @@ class T5Config(C.Structure):
 SYMBOLS = [
     "vlg_last_error", "vlg_version",
     "vlg_gpt_create", "vlg_gpt_destroy", "vlg_gpt_load_tensor", "vlg_gpt_generate",
-    "vlg_gpt_last_algorithmic_bytes", "vlg_gpt_set_option", "vlg_gpt_attn_timing", "vlg_gpt_attn_event_overhead",
+    "vlg_gpt_last_algorithmic_bytes", "vlg_gpt_graphs_built", "vlg_gpt_set_option", "vlg_gpt_attn_timing", "vlg_gpt_attn_event_overhead",
     "vlg_gpt_session_begin", "vlg_gpt_session_step", "vlg_gpt_session_read", "vlg_gpt_session_end",
     "vlg_rmsnorm", "vlg_linear", "vlg_rope_table", "vlg_sample", "vlg_attn_decode",
     "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",
-    "vlg_codebook_argmin",
+    "vlg_codebook_argmin", "vlg_codebook_forward", "vlg_causal_conv3d", "vlg_group_norm", "vlg_time_upsample2x",
     "vlg_vae_create", "vlg_vae_destroy", "vlg_vae_load_tensor", "vlg_vae_decode", "vlg_vae_out_shape",
-    "vlg_vq_encode", "vlg_vae_encode",
+    "vlg_vq_encode", "vlg_vae_encode", "vlg_tile_blend", "vlg_conv_timing", "vlg_conv_timing_read",
     "vlg_vqvae_create", "vlg_vqvae_destroy", "vlg_vqvae_load_tensor", "vlg_vqvae_decode",
     "vlg_t5_create", "vlg_t5_destroy", "vlg_t5_load_tensor", "vlg_t5_encode",
 ]

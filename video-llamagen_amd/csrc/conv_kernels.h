@@ -21,6 +21,10 @@ template <typename T>
 int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl,
                  float* out_planar, hipStream_t st);
 
+// HIP-event bracket around every halo-tile (MFMA) conv launch on its own stream; read() waits for the events and returns the sums
+int conv_timing_enable(bool on);
+int conv_timing_read(double* ms_sum, double* flop_sum, long long* launches);
+
 // GroupNorm(32 groups, eps) statistics + apply (+ swish) on channels-last data (vq_model.py:354-364, normalize.py:14-17)
 // stats: scratch of group_norm_scratch_bytes(B, P) bytes.  Statistics are reduced in a fixed order (no atomics): deterministic.
 constexpr int kGnPosPerBlock = 512;
@@ -82,5 +86,10 @@ int codebook_lookup(const float* E, const int32_t* codes, T* out, long long n, i
 // l2norm: both sides row-normalised first (vq_model.py:221-232); z row i at z + i*z_stride_row + c*z_stride_c
 int codebook_argmin(const float* z, long long z_stride_row, long long z_stride_c, long long rows_per_batch, long long z_stride_batch,
                     const float* E, long long n, int n_e, int dim, bool l2norm, int32_t* idx, hipStream_t st);
+
+// the same search on the matrix cores (exact-fp32 MFMA) for the video codebook's shapes (csrc/codebook.hip); ee_scratch: n_e floats
+bool codebook_mfma_ok(int n_e, int dim);
+int codebook_argmin_mfma(const float* z, long long z_stride_row, long long z_stride_c, long long rows_per_batch, long long z_stride_batch,
+                         const float* E, float* ee_scratch, long long n, int n_e, int dim, int32_t* idx, hipStream_t st);
 
 }  // namespace vlg

@@ -469,6 +469,51 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(ConvDesc d, const T* __
     out_planar[((p / pper) * d.Cout + co) * pper + (p % pper)] = v;
 }
 
+// ---- optional event bracket around every halo-tile conv launch (bench.py's MFMA roofline entry; off by default) ----------------
+namespace {
+struct ConvTimer {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  size_t used = 0;
+  double flops = 0;
+};
+ConvTimer& conv_timer() {
+  static ConvTimer t;
+  return t;
+}
+hipEvent_t conv_timer_event() {
+  ConvTimer& t = conv_timer();
+  if (t.used == t.ev.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    t.ev.push_back(e);
+  }
+  return t.ev[t.used++];
+}
+}  // namespace
+
+int conv_timing_enable(bool on) {
+  ConvTimer& t = conv_timer();
+  t.on = on;
+  t.used = 0;
+  t.flops = 0;
+  return VLG_OK;
+}
+int conv_timing_read(double* ms_sum, double* flop_sum, long long* launches) {
+  ConvTimer& t = conv_timer();
+  double ms = 0;
+  for (size_t i = 0; i + 1 < t.used; i += 2) {
+    VLG_HIP(hipEventSynchronize(t.ev[i + 1]));
+    float m = 0.f;
+    VLG_HIP(hipEventElapsedTime(&m, t.ev[i], t.ev[i + 1]));
+    ms += m;
+  }
+  if (ms_sum) *ms_sum = ms;
+  if (flop_sum) *flop_sum = t.flops;
+  if (launches) *launches = (long long)(t.used / 2);
+  return VLG_OK;
+}
+
 template <typename T>
 int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl, float* out_planar,
                  hipStream_t st) {
@@ -493,6 +538,19 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
         }
         attr_set = true;
       }
+      const bool timed = conv_timer().on;
+      hipEvent_t e0 = timed ? conv_timer_event() : nullptr, e1 = timed ? conv_timer_event() : nullptr;
+      if (e0 && e1) {
+        conv_timer().flops += 2.0 * (double)ptot * d.kt * d.kh * d.kw * d.Cin * d.Cout;
+        VLG_HIP(hipEventRecord(e0, st));
+      }
+      struct Stop {   // records the closing event on every exit path below
+        hipEvent_t e;
+        hipStream_t s;
+        ~Stop() {
+          if (e) (void)hipEventRecord(e, s);
+        }
+      } stop{(e0 && e1) ? e1 : nullptr, st};
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
         const long long tiles = (long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
         conv_halo_kernel<T, 1, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,

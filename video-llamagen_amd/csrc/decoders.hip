@@ -4,6 +4,7 @@
 // CausalVAEModel.decode (CausalVideoVAE/causalvideovae/model/causal_vae/modeling_causalvae.py:151-262,394-404).
 // Activations live channels-last [B,T,H,W,C] in the handle dtype; conv weights are re-laid out once at load time to
 // [Cout][taps][Cin]; GroupNorm affine params, biases and the codebook stay fp32.
+#include <algorithm>
 #include <memory>
 
 #include "conv_kernels.h"
@@ -330,12 +331,6 @@ extern "C" int vlg_vq_argmin(vlg_vq_t* h, const float* d_z, int32_t B, int32_t H
   // z is NCHW: row (b, pos) element c at b*C*hw + c*hw + pos   (the 'b c h w -> b h w c' of vq_model.py:217)
   return codebook_argmin(d_z, 1, hw, hw, (long long)C * hw, E->buf.as<float>(), (long long)B * hw, h->cfg.codebook_size, C,
                          h->cfg.l2_norm != 0, d_idx, (hipStream_t)stream);
-}
-
-extern "C" int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim, int32_t* d_idx,
-                                   void* stream) {
-  VLG_CHECK(d_z && d_codebook && d_idx && n > 0 && n_codes > 0 && dim > 0, VLG_ERR_BAD_ARG, "vlg_codebook_argmin: bad argument");
-  return codebook_argmin(d_z, dim, 1, n, 0, d_codebook, n, n_codes, dim, false, d_idx, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -705,4 +700,166 @@ extern "C" int vlg_vqvae_decode(vlg_vqvae_t* h, const int32_t* d_codes, int32_t 
   VLG_CHECK(h && d_codes && d_out && B > 0 && t > 0 && hh > 0 && ww > 0, VLG_ERR_BAD_ARG, "vlg_vqvae_decode: bad argument");
   if (h->s.dtype == VLG_BF16) return vqvae_decode_impl<bf16>(h, d_codes, B, t, hh, ww, d_out, (hipStream_t)stream);
   return vqvae_decode_impl<float>(h, d_codes, B, t, hh, ww, d_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spatial tile compositing for the tiled VAE passes (CausalVAEModel.tiled_decode2d / tiled_encode2d with blend_v / blend_h,
+// modeling_causalvae.py:424-443,491-570).  Tiles are visited in raster order; each one is cross-faded IN PLACE against the
+// finished tile above it (over its first rows) and then against the finished tile to its left (over its first columns), so that
+// later neighbours fade against the already-faded values exactly as the reference's in-place loops do; the kept top-left
+// keep_h x keep_w part lands in the output canvas in the same pass.  One thread per element, no inter-thread dependence:
+// an element only needs its own old value plus one element of each neighbour tile.
+//   weights: (float)(1 - y / e) and (float)(y / e) from double arithmetic, products and sum rounded separately (no FMA) - the
+//   rounding sequence of `a * (1 - y / e) + b * (y / e)` on fp32 tensors with Python-float scalars.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void tile_blend_kernel(float* __restrict__ tile, const float* __restrict__ above, const float* __restrict__ left,
+                                                         int64_t planes, int th, int tw, int ah, int lw, int ev, int eh, float* __restrict__ canvas,
+                                                         int ch, int cw, int y0, int x0, int keep_h, int keep_w) {
+  const int64_t n = planes * th * tw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % tw);
+    const int y = (int)((i / tw) % th);
+    const int64_t pl = i / ((int64_t)tw * th);
+    float v = tile[i];
+    if (above && y < ev) {
+      const double f = (double)y / (double)ev;
+      const float wa = (float)(1.0 - f), wb = (float)f;
+      v = __fadd_rn(__fmul_rn(above[(pl * ah + (ah - ev + y)) * tw + x], wa), __fmul_rn(v, wb));
+    }
+    if (left && x < eh) {
+      // the left neighbour's value may itself have been faded against ITS upper neighbour: it is read from the finished tile
+      const double f = (double)x / (double)eh;
+      const float wa = (float)(1.0 - f), wb = (float)f;
+      v = __fadd_rn(__fmul_rn(left[(pl * th + y) * lw + (lw - eh + x)], wa), __fmul_rn(v, wb));
+    }
+    tile[i] = v;
+    if (y < keep_h && x < keep_w) canvas[(pl * ch + (y0 + y)) * cw + (x0 + x)] = v;
+  }
+}
+}  // namespace
+
+extern "C" int vlg_tile_blend(float* d_tile, const float* d_above, const float* d_left, int64_t planes, int32_t th, int32_t tw, int32_t above_h,
+                              int32_t left_w, int32_t extent, float* d_canvas, int32_t canvas_h, int32_t canvas_w, int32_t y0, int32_t x0,
+                              int32_t keep_h, int32_t keep_w, void* stream) {
+  VLG_CHECK(d_tile && d_canvas && planes > 0 && th > 0 && tw > 0 && extent >= 0, VLG_ERR_BAD_ARG, "vlg_tile_blend: bad argument");
+  VLG_CHECK(!d_above || above_h > 0, VLG_ERR_BAD_ARG, "vlg_tile_blend: above_h must be positive when d_above is given");
+  VLG_CHECK(!d_left || left_w > 0, VLG_ERR_BAD_ARG, "vlg_tile_blend: left_w must be positive when d_left is given");
+  const int kh = std::min(keep_h, th), kw = std::min(keep_w, tw);
+  VLG_CHECK(y0 >= 0 && x0 >= 0 && kh >= 0 && kw >= 0 && y0 + kh <= canvas_h && x0 + kw <= canvas_w, VLG_ERR_BAD_SHAPE,
+            "vlg_tile_blend: kept region [%d+%d, %d+%d] exceeds the %d x %d canvas", y0, kh, x0, kw, canvas_h, canvas_w);
+  const int ev = d_above ? std::min(std::min(above_h, th), extent) : 0;
+  const int eh = d_left ? std::min(std::min(left_w, tw), extent) : 0;
+  const int64_t n = planes * th * tw;
+  const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
+  tile_blend_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(d_tile, ev > 0 ? d_above : nullptr, eh > 0 ? d_left : nullptr, planes, th, tw, above_h,
+                                                             left_w, ev, eh, d_canvas, canvas_h, canvas_w, y0, x0, kh, kw);
+  VLG_HIP(hipGetLastError());
+  return VLG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Unit entry points of the decoder kernels (per-op parity against the reference's CausalConv3d,
+// SpatialUpsample2x / SpatialDownsample2x convolutions, Normalize + swish, TimeUpsample2x).  They run the very kernels the handles
+// use on caller-provided planar fp32 tensors in the reference's layouts; scratch is a process-wide grow-only pool, so these
+// calls are for tests and tools (one host thread), not for the hot path.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct UnitScratch {
+  DevBuf xcl, wcl, ycl, stats;
+};
+UnitScratch& unit_scratch() {
+  static UnitScratch s;
+  return s;
+}
+
+template <typename T>
+int unit_conv(const float* x, const float* w, const float* b, int B, int Cin, int T_, int H, int W, int Cout, int kt, int kh, int kw, int stride,
+              int up, float* out, hipStream_t st) {
+  UnitScratch& u = unit_scratch();
+  const long long P = (long long)T_ * H * W;
+  const int taps = kt * kh * kw;
+  VLG_HIP(hipStreamSynchronize(st));
+  VLG_TRY(u.xcl.reserve((size_t)B * P * Cin * sizeof(T)));
+  VLG_TRY(u.wcl.reserve((size_t)Cout * taps * Cin * sizeof(T)));
+  VLG_TRY(planar_f32_to_cl<T>(x, u.xcl.as<T>(), B, Cin, P, st));
+  VLG_TRY(relayout_conv_weight<T>(w, u.wcl.as<T>(), Cout, Cin, taps, st));
+  ConvDesc d;
+  d.B = B; d.Ti = T_; d.Hi = H; d.Wi = W; d.Cin = Cin;
+  d.To = T_; d.Ho = (H << up) / stride; d.Wo = (W << up) / stride; d.Cout = Cout;
+  d.kt = kt; d.kh = kh; d.kw = kw;
+  d.up = up;
+  d.sh = stride;
+  if (stride == 2) d.ph0 = d.pw0 = 0;      // SpatialDownsample2x: zero pad (0,1) bottom / right only (updownsample.py:106-121)
+  return conv_forward<T>(d, u.xcl.as<T>(), u.wcl.as<T>(), b, nullptr, nullptr, out, st);
+}
+
+template <typename T>
+int unit_gn(const float* x, const float* gamma, const float* beta, int B, int C, long long P, float eps, bool swish, float* out, hipStream_t st) {
+  UnitScratch& u = unit_scratch();
+  VLG_HIP(hipStreamSynchronize(st));
+  VLG_TRY(u.xcl.reserve((size_t)B * P * C * sizeof(T)));
+  VLG_TRY(u.ycl.reserve((size_t)B * P * C * sizeof(T)));
+  VLG_TRY(u.stats.reserve(group_norm_scratch_bytes(B, P)));
+  VLG_TRY(planar_f32_to_cl<T>(x, u.xcl.as<T>(), B, C, P, st));
+  VLG_TRY(group_norm<T>(u.xcl.as<T>(), u.ycl.as<T>(), gamma, beta, u.stats.as<double>(), B, P, C, eps, swish, st));
+  return cl_to_planar_f32<T>(u.ycl.as<T>(), out, B, C, P, st);
+}
+
+template <typename T>
+int unit_timeup(const float* x, int B, int C, int T_, long long HW, float* out, hipStream_t st) {
+  UnitScratch& u = unit_scratch();
+  VLG_HIP(hipStreamSynchronize(st));
+  const int To = T_ > 1 ? 2 * T_ - 1 : 1;
+  VLG_TRY(u.xcl.reserve((size_t)B * T_ * HW * C * sizeof(T)));
+  VLG_TRY(u.ycl.reserve((size_t)B * To * HW * C * sizeof(T)));
+  VLG_TRY(planar_f32_to_cl<T>(x, u.xcl.as<T>(), B, C, (long long)T_ * HW, st));
+  if (T_ > 1) {
+    VLG_TRY(time_upsample2x<T>(u.xcl.as<T>(), u.ycl.as<T>(), B, T_, HW * C, st));
+    return cl_to_planar_f32<T>(u.ycl.as<T>(), out, B, C, (long long)To * HW, st);
+  }
+  return cl_to_planar_f32<T>(u.xcl.as<T>(), out, B, C, HW, st);
+}
+}  // namespace
+
+extern "C" int vlg_causal_conv3d(const float* d_x, const float* d_w, const float* d_bias, int32_t B, int32_t Cin, int32_t T_, int32_t H, int32_t W,
+                                 int32_t Cout, int32_t kt, int32_t kh, int32_t kw, int32_t stride_hw, int32_t nearest_up, int32_t dtype,
+                                 float* d_out, void* stream) {
+  VLG_CHECK(d_x && d_w && d_out && B > 0 && Cin > 0 && T_ > 0 && H > 0 && W > 0 && Cout > 0, VLG_ERR_BAD_ARG, "vlg_causal_conv3d: bad argument");
+  VLG_CHECK((kt == 1 || kt == 3) && (kh == 1 || kh == 3) && kh == kw, VLG_ERR_UNSUPPORTED, "vlg_causal_conv3d: kernel %dx%dx%d", kt, kh, kw);
+  VLG_CHECK((stride_hw == 1 || stride_hw == 2) && (nearest_up == 0 || nearest_up == 1) && !(stride_hw == 2 && nearest_up), VLG_ERR_UNSUPPORTED,
+            "vlg_causal_conv3d: stride %d / upsample %d", stride_hw, nearest_up);
+  if (stride_hw == 2) VLG_CHECK(kh == 3 && H % 2 == 0 && W % 2 == 0, VLG_ERR_BAD_SHAPE, "vlg_causal_conv3d: stride 2 needs a 3x3 kernel and even H, W");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VLG_BF16) return unit_conv<bf16>(d_x, d_w, d_bias, B, Cin, T_, H, W, Cout, kt, kh, kw, stride_hw, nearest_up, d_out, st);
+  if (dtype == VLG_F32) return unit_conv<float>(d_x, d_w, d_bias, B, Cin, T_, H, W, Cout, kt, kh, kw, stride_hw, nearest_up, d_out, st);
+  set_error("vlg_causal_conv3d: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vlg_group_norm(const float* d_x, const float* d_gamma, const float* d_beta, int32_t B, int32_t C, int64_t P, float eps, int32_t swish,
+                              int32_t dtype, float* d_out, void* stream) {
+  VLG_CHECK(d_x && d_gamma && d_beta && d_out && B > 0 && C > 0 && C % 32 == 0 && P > 0, VLG_ERR_BAD_ARG, "vlg_group_norm: bad argument (32 groups)");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VLG_BF16) return unit_gn<bf16>(d_x, d_gamma, d_beta, B, C, P, eps, swish != 0, d_out, st);
+  if (dtype == VLG_F32) return unit_gn<float>(d_x, d_gamma, d_beta, B, C, P, eps, swish != 0, d_out, st);
+  set_error("vlg_group_norm: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vlg_time_upsample2x(const float* d_x, int32_t B, int32_t C, int32_t T_, int64_t HW, int32_t dtype, float* d_out, void* stream) {
+  VLG_CHECK(d_x && d_out && B > 0 && C > 0 && T_ > 0 && HW > 0, VLG_ERR_BAD_ARG, "vlg_time_upsample2x: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VLG_BF16) return unit_timeup<bf16>(d_x, B, C, T_, HW, d_out, st);
+  if (dtype == VLG_F32) return unit_timeup<float>(d_x, B, C, T_, HW, d_out, st);
+  set_error("vlg_time_upsample2x: dtype %d", dtype);
+  return VLG_ERR_UNSUPPORTED;
+}
+
+extern "C" int vlg_conv_timing(int32_t enable) { return conv_timing_enable(enable != 0); }
+extern "C" int vlg_conv_timing_read(double* ms_sum, double* flop_sum, int64_t* launches) {
+  long long n = 0;
+  VLG_TRY(conv_timing_read(ms_sum, flop_sum, &n));
+  if (launches) *launches = n;
+  return VLG_OK;
 }

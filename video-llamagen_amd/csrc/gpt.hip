@@ -23,6 +23,14 @@ struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
   DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
+  DevBuf maskbuf;                                           // this lane's rows of the caller's emb_mask (stable address for the cached graph)
+  std::vector<uint64_t> ptr_key() const {                   // every address a captured decode step can hold
+    std::vector<uint64_t> k;
+    for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &attn_cnt, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
+                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf})
+      k.push_back((uint64_t)(uintptr_t)b->p);
+    return k;
+  }
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
   ~Lane() {
@@ -61,6 +69,25 @@ struct vlg_gpt {
   hipStream_t s_int = nullptr;   // weight uploads
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
   bool use_graph = true;
+  // The instantiated decode-step graph of the last generate(), reused while every value and address baked into it is unchanged
+  // (shape, sampling parameters, options, lane buffers, noise / trace pointers).  Outputs go through `outbuf` (handle-owned, stable
+  // address) and are copied to the caller's buffer on the caller's stream at the end, so fresh output tensors do not invalidate it.
+  struct GraphCache {
+    std::vector<uint64_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;   // the stream its launches were enqueued on
+    void drop() {
+      if (stream) (void)hipStreamSynchronize(stream);
+      if (exec) (void)hipGraphExecDestroy(exec);
+      if (graph) (void)hipGraphDestroy(graph);
+      exec = nullptr;
+      graph = nullptr;
+      key.clear();
+    }
+  } gc;
+  DevBuf outbuf;                     // [B, N] int32 ids or [B, N, C] fp32 latents of the running call
+  long long graphs_built = 0;        // instantiations so far (tests: a repeated call must not add one)
   bool attn_inlaunch = false;        // split-KV partials merged by the last-arriving workgroup instead of a combine launch
                                      // (r01: 22.96 s vs 21.81 s/step - the ticket's round trip stalls every workgroup's exit)
   bool splitk_inlaunch = false;      // residual GEMMs: K split over workgroups, combined in-launch by the last arriver
@@ -76,6 +103,7 @@ struct vlg_gpt {
   double bytes_w = 0, bytes_kv = 0, bytes_other = 0;
 
   ~vlg_gpt() {
+    gc.drop();
     if (s_int) (void)hipStreamDestroy(s_int);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
@@ -373,6 +401,12 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
   }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
+}
+
+extern "C" int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count) {
+  VLG_CHECK(h && count, VLG_ERR_BAD_ARG, "vlg_gpt_graphs_built: null argument");
+  *count = h->graphs_built;
+  return VLG_OK;
 }
 
 extern "C" int vlg_gpt_attn_event_overhead(vlg_gpt_t* h, double* ms_per_pair) {
@@ -876,13 +910,22 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   if (nl > B) nl = B;
   if (nl > 4) nl = 4;
   while ((int)h->lanes.size() < nl) h->lanes.emplace_back(new Lane());
+  const bool latent_out = h->cfg.head != VLG_HEAD_LOGITS;
+  const size_t out_bytes = latent_out ? (size_t)B * N * h->C * sizeof(float) : (size_t)B * N * sizeof(int32_t);
+  void* user_out = latent_out ? (void*)out_lat : (void*)out_ids;
+  VLG_TRY(h->outbuf.reserve(out_bytes));
+  if (latent_out)
+    out_lat = h->outbuf.as<float>();
+  else
+    out_ids = h->outbuf.as<int32_t>();
   std::vector<Runner<T>> rs;
   for (int i = 0; i < nl; ++i) {
     const int lo = (int)((long long)B * i / nl), hi = (int)((long long)B * (i + 1) / nl);
     const int Bl = hi - lo, Bpl = cfg_on ? 2 * Bl : Bl;
     Lane* ln = h->lanes[i].get();
     VLG_TRY(reserve_lane(h, *ln, Bl, Bpl, S));
-    rs.push_back(Runner<T>{h, ln, ln->st, Bl, Bpl, N, S, lo, B, d_mask ? d_mask + (size_t)lo * Tc : nullptr});
+    if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)Bl * Tc * sizeof(float)));
+    rs.push_back(Runner<T>{h, ln, ln->st, Bl, Bpl, N, S, lo, B, d_mask ? ln->maskbuf.as<float>() : nullptr});
   }
   h->last_lanes = nl;
   if (h->cfg.head == VLG_HEAD_HIDDEN) {
@@ -892,7 +935,11 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
 
   // ---- fork from the caller's stream ----------------------------------------------------------------------------
   VLG_HIP(hipEventRecord(h->ev_in, caller));
-  for (auto& r : rs) VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
+  for (auto& r : rs) {
+    VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
+    if (d_mask)
+      VLG_HIP(hipMemcpyAsync(r.ln->maskbuf.p, d_mask + (size_t)r.b0 * Tc, (size_t)r.B * Tc * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  }
   for (auto& r : rs) VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   hipStream_t s0 = rs[0].st;
   const int steps = N - 1;
@@ -937,43 +984,61 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
       }
     } else if (h->use_graph) {
       // one graph = one decode step of every lane, lanes on parallel branches (fork/join on lane 0's stream)
-      hipGraph_t graph = nullptr;
-      hipGraphExec_t exec = nullptr;
-      for (size_t i = 1; i < rs.size(); ++i) {  // order the other lanes' prefill before the captured region
+      for (size_t i = 1; i < rs.size(); ++i) {  // order the other lanes' prefill before the graph launches
         VLG_HIP(hipEventRecord(rs[i].ln->ev, rs[i].st));
         VLG_HIP(hipStreamWaitEvent(s0, rs[i].ln->ev, 0));
       }
-      VLG_HIP(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
-      int rc = VLG_OK;
-      hipError_t ce = hipSuccess;
-      if (rs.size() > 1) {
-        ce = hipEventRecord(h->ev_fork, s0);
-        for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) ce = hipStreamWaitEvent(rs[i].st, h->ev_fork, 0);
+      auto fbits = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        return (uint64_t)u;
+      };
+      std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)N, (uint64_t)nl, (uint64_t)S, (uint64_t)h->dtype, fbits(sp.cfg_scale),
+                                   (uint64_t)(int64_t)sp.cfg_interval, fbits(sp.temperature), (uint64_t)(int64_t)sp.top_k, fbits(sp.top_p),
+                                   (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
+                                   (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
+                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->fuse_qkv ? 4 : 0) | (h->attn_inlaunch ? 8 : 0) |
+                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0))};
+      for (auto& r : rs) {
+        key.push_back((uint64_t)(uintptr_t)r.st);
+        const auto pk = r.ln->ptr_key();
+        key.insert(key.end(), pk.begin(), pk.end());
       }
-      for (size_t i = 0; i < rs.size() && rc == VLG_OK && ce == hipSuccess; ++i) rc = rs[i].decode_step(sp, d_noise, out_ids, out_lat, trace);
-      for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) {
-        ce = hipEventRecord(rs[i].ln->ev, rs[i].st);
-        if (ce == hipSuccess) ce = hipStreamWaitEvent(s0, rs[i].ln->ev, 0);
-      }
-      hipError_t ee = hipStreamEndCapture(s0, &graph);
-      if (rc != VLG_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
-      }
-      VLG_HIP(ce);
-      VLG_HIP(ee);
-      VLG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      for (int i = 0; i < steps; ++i) {
-        hipError_t le = hipGraphLaunch(exec, s0);
-        if (le != hipSuccess) {
-          (void)hipGraphExecDestroy(exec);
-          (void)hipGraphDestroy(graph);
-          VLG_HIP(le);
+      if (!h->gc.exec || h->gc.key != key) {
+        h->gc.drop();
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        VLG_HIP(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+        int rc = VLG_OK;
+        hipError_t ce = hipSuccess;
+        if (rs.size() > 1) {
+          ce = hipEventRecord(h->ev_fork, s0);
+          for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) ce = hipStreamWaitEvent(rs[i].st, h->ev_fork, 0);
         }
+        for (size_t i = 0; i < rs.size() && rc == VLG_OK && ce == hipSuccess; ++i) rc = rs[i].decode_step(sp, d_noise, out_ids, out_lat, trace);
+        for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) {
+          ce = hipEventRecord(rs[i].ln->ev, rs[i].st);
+          if (ce == hipSuccess) ce = hipStreamWaitEvent(s0, rs[i].ln->ev, 0);
+        }
+        hipError_t ee = hipStreamEndCapture(s0, &graph);
+        if (rc != VLG_OK) {
+          if (graph) (void)hipGraphDestroy(graph);
+          return rc;
+        }
+        VLG_HIP(ce);
+        VLG_HIP(ee);
+        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+          (void)hipGraphDestroy(graph);
+          VLG_HIP(ie);
+        }
+        h->gc.graph = graph;
+        h->gc.exec = exec;
+        h->gc.key = key;
+        h->gc.stream = s0;
+        h->graphs_built += 1;
       }
-      VLG_HIP(hipStreamSynchronize(s0));
-      (void)hipGraphExecDestroy(exec);
-      (void)hipGraphDestroy(graph);
+      for (int i = 0; i < steps; ++i) VLG_HIP(hipGraphLaunch(h->gc.exec, s0));   // no host wait: the call returns with the work enqueued
     } else {
       for (int i = 0; i < steps; ++i)
         for (auto& r : rs) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
@@ -984,6 +1049,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     VLG_HIP(hipEventRecord(r.ln->ev, r.st));
     VLG_HIP(hipStreamWaitEvent(caller, r.ln->ev, 0));
   }
+  VLG_HIP(hipMemcpyAsync(user_out, h->outbuf.p, out_bytes, hipMemcpyDeviceToDevice, caller));
 
   // ---- algorithmic bytes of this call; weights are streamed once per lane and step ------------------
   const int Bp = cfg_on ? 2 * B : B;

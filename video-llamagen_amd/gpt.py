@@ -261,6 +261,12 @@ class Transformer:
         L.check(L.lib().vlg_gpt_attn_timing(self._handle, C.byref(ms), C.byref(by), C.byref(n)))
         return ms.value, by.value, n.value
 
+    def graphs_built(self):
+        """decode-step graphs instantiated by this handle so far (a repeated generate() of the same shape must not add one)."""
+        n = C.c_int64()
+        L.check(L.lib().vlg_gpt_graphs_built(self._handle, C.byref(n)))
+        return n.value
+
     def attn_event_overhead_ms(self):
         """mean elapsed ms of an empty event pair on the launch stream (calibration of the timing bracket)."""
         ms = C.c_double()

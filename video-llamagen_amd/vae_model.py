@@ -187,61 +187,75 @@ class CausalVAEModel:
             return self.tiled_decode(z)
         return self._decode_plain(z)
 
-    # ---- tiling (modeling_causalvae.py:424-443,468-570): host-level orchestration over plain decodes; tiles overlap and are
-    # blended linearly, temporal chunks overlap by one latent frame whose first decoded frame is dropped ----------------------
+    # ---- tiling (what modeling_causalvae.py:424-570 computes) ------------------------------------------------------------
+    # Time: the clip is cut into windows that share one frame; every window after the first contributes everything but its first
+    # output frame.  Space: overlapping square tiles in raster order; libvlg's vlg_tile_blend cross-fades each finished tile in place
+    # against its upper and left neighbours and writes the part that is kept straight into the output canvas (no Python per-row
+    # loops, no torch.cat of cropped tiles).
     @staticmethod
-    def blend_v(a, b, blend_extent):
-        blend_extent = min(a.shape[3], b.shape[3], blend_extent)
-        for y in range(blend_extent):
-            b[:, :, :, y, :] = a[:, :, :, -blend_extent + y, :] * (1 - y / blend_extent) + b[:, :, :, y, :] * (y / blend_extent)
-        return b
+    def _time_windows(length, window):
+        """[lo, hi) windows of `window` frames at stride window - 1 (adjacent windows share a frame); a tail shorter than a full
+        window becomes its own window, one that would overrun is clipped."""
+        starts = list(range(0, length, window - 1))
+        if len(starts) == 1:
+            return [(0, length)]
+        spans = [[lo, nxt + 1] for lo, nxt in zip(starts[:-1], starts[1:])]
+        if spans[-1][1] > length:
+            spans[-1][1] = length
+        elif spans[-1][1] < length:
+            spans.append([starts[-1], length])
+        return [tuple(sp) for sp in spans]
 
-    @staticmethod
-    def blend_h(a, b, blend_extent):
-        blend_extent = min(a.shape[4], b.shape[4], blend_extent)
-        for x in range(blend_extent):
-            b[:, :, :, :, x] = a[:, :, :, :, -blend_extent + x] * (1 - x / blend_extent) + b[:, :, :, :, x] * (x / blend_extent)
-        return b
+    def _composite(self, x, tile_in, stride_in, run, extent, keep):
+        """Runs `run` on every tile_in x tile_in window of x's last two axes (raster order, stride stride_in) and assembles the
+        blended result: each tile fades over `extent` cells into the tiles above / left of it and contributes its first `keep`
+        rows and columns."""
+        ys = list(range(0, x.shape[3], stride_in))
+        xs = list(range(0, x.shape[4], stride_in))
+        lib = L.lib()
+        st = L.stream_ptr(self._device)
+        done = {}                    # (row, col) -> finished (already faded) tile: the row above and the current row stay alive
+        canvas = None
+        cy = 0
+        for r, y_in in enumerate(ys):
+            cx = 0
+            for c, x_in in enumerate(xs):
+                tile = run(x[:, :, :, y_in:y_in + tile_in, x_in:x_in + tile_in]).contiguous()
+                Bq, Cq, Tq, th, tw = [int(v) for v in tile.shape]
+                if canvas is None:
+                    # every tile of a row has the same height and every tile of a column the same width, so the canvas size
+                    # follows from the first tile's scale factor
+                    fy, fx = th / min(tile_in, x.shape[3]), tw / min(tile_in, x.shape[4])
+                    Hc = sum(min(keep, int(round(fy * min(tile_in, x.shape[3] - yy)))) for yy in ys)
+                    Wc = sum(min(keep, int(round(fx * min(tile_in, x.shape[4] - xx)))) for xx in xs)
+                    canvas = torch.empty((Bq, Cq, Tq, Hc, Wc), dtype=torch.float32, device=self._device)
+                up = done.get((r - 1, c))
+                lf = done.get((r, c - 1))
+                with torch.cuda.device(self._device):
+                    L.check(lib.vlg_tile_blend(L.ptr(tile), L.ptr(up), L.ptr(lf), C.c_int64(Bq * Cq * Tq), th, tw,
+                                               0 if up is None else int(up.shape[3]), 0 if lf is None else int(lf.shape[4]), extent,
+                                               L.ptr(canvas), int(canvas.shape[3]), int(canvas.shape[4]), cy, cx, keep, keep, st))
+                done[(r, c)] = tile
+                cx += min(keep, tw)
+                row_h = min(keep, th)
+            for c in range(len(xs)):
+                done.pop((r - 1, c), None)
+            cy += row_h
+        return canvas
 
-    def tiled_decode(self, x):
-        t = x.shape[2]
-        t_chunk_idx = [i for i in range(0, t, self.tile_latent_min_size_t - 1)]
-        if len(t_chunk_idx) == 1 and t_chunk_idx[0] == 0:
-            t_chunk_start_end = [[0, t]]
-        else:
-            t_chunk_start_end = [[t_chunk_idx[i], t_chunk_idx[i + 1] + 1] for i in range(len(t_chunk_idx) - 1)]
-            if t_chunk_start_end[-1][-1] > t:
-                t_chunk_start_end[-1][-1] = t
-            elif t_chunk_start_end[-1][-1] < t:
-                t_chunk_start_end.append([t_chunk_idx[-1], t])
-        dec_ = []
-        for idx, (start, end) in enumerate(t_chunk_start_end):
-            dec = self.tiled_decode2d(x[:, :, start:end])
-            dec_.append(dec[:, :, 1:] if idx != 0 else dec)
-        return torch.cat(dec_, dim=2)
+    def tiled_decode(self, z):
+        parts = []
+        for n, (lo, hi) in enumerate(self._time_windows(z.shape[2], self.tile_latent_min_size_t)):
+            frames = self.tiled_decode2d(z[:, :, lo:hi])
+            parts.append(frames if n == 0 else frames[:, :, 1:])
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
 
     def tiled_decode2d(self, z):
-        overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
-        blend_extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
-        row_limit = self.tile_sample_min_size - blend_extent
-        rows = []
-        for i in range(0, z.shape[3], overlap_size):
-            row = []
-            for j in range(0, z.shape[4], overlap_size):
-                tile = z[:, :, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size]
-                row.append(self._decode_plain(tile))          # post_quant_conv + decoder on the GPU (libvlg)
-            rows.append(row)
-        result_rows = []
-        for i, row in enumerate(rows):
-            result_row = []
-            for j, tile in enumerate(row):
-                if i > 0:
-                    tile = self.blend_v(rows[i - 1][j], tile, blend_extent)
-                if j > 0:
-                    tile = self.blend_h(row[j - 1], tile, blend_extent)
-                result_row.append(tile[:, :, :, :row_limit, :row_limit])
-            result_rows.append(torch.cat(result_row, dim=4))
-        return torch.cat(result_rows, dim=3)
+        """Latent tiles of tile_latent_min_size cells at stride size*(1-overlap); decoded tiles fade over tile_sample_min_size*overlap
+        pixels and keep tile_sample_min_size minus that many."""
+        fade = int(self.tile_sample_min_size * self.tile_overlap_factor)
+        return self._composite(z.to(self._device), self.tile_latent_min_size, int(self.tile_latent_min_size * (1 - self.tile_overlap_factor)),
+                               self._decode_plain, fade, self.tile_sample_min_size - fade)
 
     @torch.no_grad()
     def encode(self, x):
@@ -256,44 +270,21 @@ class CausalVAEModel:
 
     @torch.no_grad()
     def tiled_encode(self, x):
-        """modeling_causalvae.py:444-466: temporal chunks of tile_sample_min_size_t frames sharing one frame (the repeated latent frame
-        of every later chunk is dropped), each chunk tiled spatially by tiled_encode2d."""
-        t = x.shape[2]
-        starts = list(range(0, t, self.tile_sample_min_size_t - 1))
-        if len(starts) == 1:
-            spans = [[0, t]]
-        else:
-            spans = [[starts[i], starts[i + 1] + 1] for i in range(len(starts) - 1)]
-            if spans[-1][1] > t:
-                spans[-1][1] = t
-            elif spans[-1][1] < t:
-                spans.append([starts[-1], t])
+        """modeling_causalvae.py:444-466: windows of tile_sample_min_size_t frames sharing one frame (the repeated latent frame of
+        every later window is dropped), each window tiled spatially by tiled_encode2d."""
         parts = []
-        for n, (a, b) in enumerate(spans):
-            mom = self.tiled_encode2d(x[:, :, a:b], return_moments=True)
+        for n, (lo, hi) in enumerate(self._time_windows(x.shape[2], self.tile_sample_min_size_t)):
+            mom = self.tiled_encode2d(x[:, :, lo:hi], return_moments=True)
             parts.append(mom if n == 0 else mom[:, :, 1:])
-        return DiagonalGaussianDistribution(torch.cat(parts, dim=2))
+        return DiagonalGaussianDistribution(parts[0] if len(parts) == 1 else torch.cat(parts, dim=2))
 
     @torch.no_grad()
     def tiled_encode2d(self, x, return_moments=False):
         """modeling_causalvae.py:491-530: tile_sample_min_size-pixel tiles at stride size*(1-overlap), moments of neighbouring tiles
-        blended over tile_latent_min_size*overlap latent cells, each tile cropped to the stride in latent cells."""
-        stride = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
-        extent = int(self.tile_latent_min_size * self.tile_overlap_factor)
-        keep = self.tile_latent_min_size - extent
-        grid = [[self._encode_moments(x[:, :, :, i:i + self.tile_sample_min_size, j:j + self.tile_sample_min_size])
-                 for j in range(0, x.shape[4], stride)] for i in range(0, x.shape[3], stride)]
-        out_rows = []
-        for i, row in enumerate(grid):
-            cells = []
-            for j, tile in enumerate(row):
-                if i > 0:
-                    tile = self.blend_v(grid[i - 1][j], tile, extent)
-                if j > 0:
-                    tile = self.blend_h(row[j - 1], tile, extent)
-                cells.append(tile[:, :, :, :keep, :keep])
-            out_rows.append(torch.cat(cells, dim=4))
-        moments = torch.cat(out_rows, dim=3)
+        faded over tile_latent_min_size*overlap latent cells, each tile keeping tile_latent_min_size minus that many."""
+        fade = int(self.tile_latent_min_size * self.tile_overlap_factor)
+        moments = self._composite(x.to(self._device), self.tile_sample_min_size, int(self.tile_sample_min_size * (1 - self.tile_overlap_factor)),
+                                  self._encode_moments, fade, self.tile_latent_min_size - fade)
         return moments if return_moments else DiagonalGaussianDistribution(moments)
 
     def _encode_moments(self, x):

@@ -10,6 +10,55 @@ from . import _lib as L
 from .vq_model import codebook_argmin
 
 
+class Codebook:
+    """Codebook in eval mode (tokenizer/tokenizer_video/vqvae.py:130-213 == CausalVideoVAE/causalvideovae/model/modules/quant.py:8-100):
+    `forward(z[b,c,t,h,w]) -> dict(embeddings, encodings, commitment_loss, perplexity)`, `dictionary_lookup(encodings)`.  The EMA
+    update and the data-dependent initialisation only exist in training and are not part of this path."""
+
+    def __init__(self, n_codes, embedding_dim):
+        self.n_codes, self.embedding_dim = n_codes, embedding_dim
+        self.embeddings = None
+        self.training = False
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if self.embeddings is not None and device is not None and not isinstance(device, torch.dtype):
+            self.embeddings = self.embeddings.to(device)
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        e = state_dict["embeddings"].detach().to(torch.float32)
+        if tuple(e.shape) != (self.n_codes, self.embedding_dim):
+            raise L.VlgError(-2, "size mismatch for embeddings: %s vs (%d, %d)" % (tuple(e.shape), self.n_codes, self.embedding_dim))
+        self.embeddings = e.to("cuda").contiguous()
+        return [], [k for k in state_dict if k != "embeddings"]      # N / z_avg: EMA statistics, training only
+
+    @torch.no_grad()
+    def forward(self, z):
+        if self.embeddings is None:
+            raise L.VlgError(-6, "embeddings was never loaded")
+        if z.dim() != 5 or z.shape[1] != self.embedding_dim:
+            raise L.VlgError(-2, "z must be [b, %d, t, h, w], got %s" % (self.embedding_dim, tuple(z.shape)))
+        dev = self.embeddings.device
+        zf = z.to(dev, torch.float32).contiguous()
+        B, Cc = int(z.shape[0]), int(z.shape[1])
+        n_pos = int(z.shape[2] * z.shape[3] * z.shape[4])
+        enc = torch.empty((B,) + tuple(z.shape[2:]), dtype=torch.int32, device=dev)
+        emb = torch.empty_like(zf)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().vlg_codebook_forward(L.ptr(zf), L.ptr(self.embeddings), B, Cc, C.c_int64(n_pos), self.n_codes, L.ptr(enc), L.ptr(emb),
+                                                 L.ptr(stats), L.stream_ptr(dev)))
+        return dict(embeddings=emb, encodings=enc.long(), commitment_loss=stats[0], perplexity=stats[1])
+
+    __call__ = forward
+
+    def dictionary_lookup(self, encodings):
+        return torch.nn.functional.embedding(encodings.to(self.embeddings.device), self.embeddings)
+
+
 class VQVAE:
     def __init__(self, args=None, **kw):
         a = dict(embedding_dim=256, n_codes=2048, n_hiddens=240, n_res_layers=4, downsample=(4, 4, 4))   # vqvae.py:78-86
