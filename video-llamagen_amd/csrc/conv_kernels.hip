@@ -494,9 +494,11 @@ hipEvent_t conv_timer_event() {
 
 int conv_timing_enable(bool on) {
   ConvTimer& t = conv_timer();
+  if (on) {          // a new measurement starts; switching off keeps what was recorded for conv_timing_read
+    t.used = 0;
+    t.flops = 0;
+  }
   t.on = on;
-  t.used = 0;
-  t.flops = 0;
   return VLG_OK;
 }
 int conv_timing_read(double* ms_sum, double* flop_sum, long long* launches) {
