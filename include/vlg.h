@@ -118,7 +118,8 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "fuse_qkv" (0: RoPE + KV append inside attention),
- * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "lanes" (0 = auto:
+ * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "gemm_lds" (0: decode GEMMs
+ * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto:
  * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
 /* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last

@@ -330,6 +330,20 @@ def test_unfused_gemm_path_matches_fused(golden, tag, cfg, dt):
         assert (a.cpu().numpy() == golden("gpt")[f"{tag}_fp32_cfg_ids"]).all()
 
 
+@pytest.mark.parametrize("tag,cfg", [("c2i", cases.TINY_C2I), ("t2i", cases.TINY_T2I)])
+def test_lds_gemm_path_vs_reference_golden(golden, tag, cfg):
+    """The optional LDS-DMA decode GEMMs (gemm_lds = True) against the reference's ids / logits (fp32: greedy ids bit-exact)."""
+    import video_llamagen_amd as V
+    g = golden("gpt")
+    m, _ = product_gpt(cfg, torch.float32)
+    m.gemm_lds = True
+    cond, masks = _inputs(cfg)
+    N = cfg["block_size"]
+    ids, tr = V.generate(m, cond, N, masks, cfg_scale=2.5, cfg_interval=6, sample_logits=False, return_trace=True)
+    np.testing.assert_allclose(to_np(tr), g[f"{tag}_fp32_cfg_logits"], atol=3e-4, rtol=1e-4)
+    assert (ids.cpu().numpy() == g[f"{tag}_fp32_cfg_ids"]).all()
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_batch_lanes_do_not_change_results(golden, lanes):
     """The batch is split into independent lanes (forked graph branches) purely for overlap: every lane count must
@@ -451,6 +465,16 @@ def test_full_width_decode_paths_agree():
     sk = V.generate_t2v(m, cond, 40, mask)
     _lib.check(_lib.lib().vlg_gpt_set_option(m._handle, b"splitk_inlaunch", C.c_int64(0)))
     assert torch.isfinite(sk).all() and torch.equal(sk[:, 0], a[:, 0]) and (sk[:, :3] - a[:, :3]).abs().max().item() < 2e-2 * a.abs().max().item()
+    # LDS-DMA form of the decode GEMMs (operands staged by global_load_lds, row statistics handed from kernel to kernel): same
+    # rounding points, other fp32 summation order
+    m.gemm_lds = True
+    lds = V.generate_t2v(m, cond, 40, mask)
+    assert torch.isfinite(lds).all() and torch.equal(lds, V.generate_t2v(m, cond, 40, mask))
+    assert (lds[:, :3] - a[:, :3]).abs().max().item() < 2e-2 * a.abs().max().item()
+    lds64 = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)          # 64 rows: two 32-row workgroups per n-tile
+    m.gemm_lds = False
+    ref64 = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
+    assert (lds64[:, :3] - ref64[:, :3]).abs().max().item() < 3e-2 * max(a.abs().max().item(), ref64.abs().max().item())
     m.fuse_gemm = False
     c = V.generate_t2v(m, cond, 40, mask)
     m.fuse_qkv = True

@@ -70,6 +70,58 @@ __global__ __launch_bounds__(64 * NW) void load_kernel(const unsigned short* __r
       for (int p = wave; p < 16 * ppr; p += NW)
         acc ^= __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w + (size_t)(n0 + p / ppr) * K + (p % ppr) * 512) + lane);
     }
+  } else if constexpr (MODE == 5 || MODE == 6 || MODE == 7) {
+    // 4 x 256 B pieces; MODE 5: all X pieces, then all W pieces (per wave), K order rotated by the workgroup index;
+    // MODE 6: the same without rotation; MODE 7: dedicated waves - waves 0..2 stream W, waves 3..7 stream X (rotated)
+    const int nkg = K / 128;
+    const int px = (WHAT & 2) ? M / 4 : 0, pw = (WHAT & 1) ? 4 : 0;
+    const int lr = lane >> 4, lc = lane & 15;
+    const int rot = (MODE == 6) ? 0 : (int)(blockIdx.x % nkg);
+    auto ldx = [&](int p, int slot) {   // X piece p = kg * px + g
+      const int kg = (p / px + rot) % nkg, g = p % px;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(x + (size_t)(g * 4 + lr) * K + (size_t)kg * 128 + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + (size_t)slot * 1024), 16, 0, 0);
+    };
+    auto ldw = [&](int p, int slot) {
+      const int kg = (p / pw + rot) % nkg, g = p % pw;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(w + (size_t)(n0 + g * 4 + lr) * K + (size_t)kg * 128 + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + (size_t)slot * 1024), 16, 0, 2);
+    };
+    const int nxp = nkg * px, nwp = nkg * pw;
+    if constexpr (MODE == 7) {
+      const int WW = 3, XW = NW - WW;
+      if (wave < WW) {
+        for (int p = wave; p < nwp; p += WW) ldw(p, nxp + p);
+      } else {
+        for (int p = wave - WW; p < nxp; p += XW) ldx(p, p);
+      }
+    } else {
+      for (int p = wave; p < nxp; p += NW) ldx(p, p);
+      for (int p = wave; p < nwp; p += NW) ldw(p, nxp + p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s2 = wave; s2 < nxp + nwp; s2 += NW) acc ^= reinterpret_cast<const u32x4*>(lds + (size_t)s2 * 1024)[lane];
+  } else if constexpr (MODE == 3 || MODE == 4) {
+    // the GEMM kernel's order: per K group, the X pieces then the W pieces; a piece = RP rows x (1024 / RP) bytes
+    constexpr int RP = MODE == 3 ? 4 : 2;          // rows per piece
+    constexpr int SEG = 1024 / RP;                 // bytes per row segment
+    const int nseg = K * 2 / SEG;                  // K groups
+    const int px = (WHAT & 2) ? M / RP : 0, pw = (WHAT & 1) ? 16 / RP : 0, pp = px + pw;
+    const int lr = lane / (SEG / 16), lc = lane % (SEG / 16);
+    int slot = wave;
+    for (int p = wave; p < nseg * pp; p += NW, slot += NW) {
+      const int kg = p / pp, g = p - kg * pp;
+      const unsigned short* src = g < px ? x + (size_t)(g * RP + lr) * K + (size_t)kg * (SEG / 2) + lc * 8
+                                         : w + (size_t)(n0 + (g - px) * RP + lr) * K + (size_t)kg * (SEG / 2) + lc * 8;
+      if (g < px)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(src), (__attribute__((address_space(3))) void*)(lds + (size_t)slot * 1024), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(src), (__attribute__((address_space(3))) void*)(lds + (size_t)slot * 1024), 16, 0, 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s2 = wave; s2 < nseg * pp; s2 += NW) acc ^= reinterpret_cast<const u32x4*>(lds + (size_t)s2 * 1024)[lane];
   } else {
     const int ppr = K / 512;
     int slot = wave;   // LDS piece index; NW pieces are written per round
@@ -99,7 +151,7 @@ __global__ void fill_kernel(unsigned short* p, size_t n, unsigned seed) {
 
 template <int MODE, int WHAT, int NW>
 float run(const char* name, const std::vector<unsigned short*>& ws, unsigned short* x, int M, int N, int K, unsigned* out, hipStream_t st) {
-  const size_t ldsb = MODE == 2 ? (size_t)(((WHAT & 2) ? M : 0) + ((WHAT & 1) ? 16 : 0)) * K * 2 : 0;
+  const size_t ldsb = MODE >= 2 ? (size_t)(((WHAT & 2) ? M : 0) + ((WHAT & 1) ? 16 : 0)) * K * 2 : 0;
   if (ldsb > 160 * 1024) {
     printf("%-44s skipped (%zu KB LDS)\n", name, ldsb / 1024);
     return 0;
@@ -153,7 +205,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&x, (size_t)M * sh.K * 2));
     fill_kernel<<<64, 256>>>(x, (size_t)M * sh.K, 99);
     CK(hipDeviceSynchronize());
-    printf("---- %s: N %d, K %d, M %d, %d workgroups ----\n", sh.n, sh.N, sh.K, M, sh.N / 16);
+    printf("---- %s: N %d, K %d, M %d, %d workgroups (\"rows\" modes cover %d of %d K elements) ----\n", sh.n, sh.N, sh.K, M, sh.N / 16, sh.K / 512 * 512, sh.K);
     char nm[96];
 #define RUN(MODE, WHAT, NW, label)                                              \
   snprintf(nm, sizeof nm, "%s [%s] %d waves", label, #WHAT, NW);                \
@@ -170,6 +222,18 @@ int main(int argc, char** argv) {
     RUN(2, 1, 4, "LDS-DMA rows, W only");
     RUN(2, 2, 4, "LDS-DMA rows, X only");
     RUN(2, 3, 8, "LDS-DMA rows, W+X");
+    RUN(3, 3, 8, "LDS-DMA 4x256B pieces, K-major, W+X");
+    RUN(3, 1, 8, "LDS-DMA 4x256B pieces, K-major, W only");
+    RUN(3, 2, 8, "LDS-DMA 4x256B pieces, K-major, X only");
+    RUN(6, 3, 8, "LDS-DMA 4x256B, X then W, W+X");
+    RUN(5, 3, 8, "LDS-DMA 4x256B, X then W, rotated, W+X");
+    RUN(5, 2, 8, "LDS-DMA 4x256B, rotated, X only");
+    RUN(6, 2, 8, "LDS-DMA 4x256B, X only");
+    RUN(7, 3, 8, "LDS-DMA 4x256B, dedicated waves 3W+5X, rotated");
+    RUN(4, 3, 8, "LDS-DMA 2x512B pieces, K-major, W+X");
+    RUN(4, 1, 8, "LDS-DMA 2x512B pieces, K-major, W only");
+    RUN(2, 1, 8, "LDS-DMA rows, W only");
+    RUN(2, 2, 8, "LDS-DMA rows, X only");
     for (auto p : ws) CK(hipFree(p));
     CK(hipFree(x));
   }

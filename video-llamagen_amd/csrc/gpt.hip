@@ -23,11 +23,12 @@ struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
   DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
+  DevBuf rowsq;                                             // [D/16][64-padded rows] per-tile sums of squares of the residual stream (FusedGemm::sq_*)
   DevBuf maskbuf;                                           // this lane's rows of the caller's emb_mask (stable address for the cached graph)
   std::vector<uint64_t> ptr_key() const {                   // every address a captured decode step can hold
     std::vector<uint64_t> k;
     for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &attn_cnt, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
-                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf})
+                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf, &rowsq})
       k.push_back((uint64_t)(uintptr_t)b->p);
     return k;
   }
@@ -93,6 +94,8 @@ struct vlg_gpt {
   bool splitk_inlaunch = false;      // residual GEMMs: K split over workgroups, combined in-launch by the last arriver
   bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
+  bool gemm_lds = false;             // decode GEMMs on the LDS-DMA kernel + row statistics handed from producer to consumer (r02: equal in the
+                                     // GEMM-chain microbenchmark, 8 % slower in the step at short context - DESIGN.md section 5 - so off)
   bool fuse_qkv = false;             // decode: RoPE + KV append inside the attention kernel (r01: +4 us/layer vs the separate
                                      // scatter kernel - 111 VGPRs and a dependent prologue - so off by default)
   bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
@@ -394,6 +397,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->fuse_qkv = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "gemm_lds")) {
+    h->gemm_lds = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "lanes")) {
     VLG_CHECK(value >= 0 && value <= 4, VLG_ERR_BAD_ARG, "lanes must be 0 (auto) .. 4");
     h->lanes_opt = (int)value;
@@ -511,10 +518,22 @@ struct Runner {
   }
 
   // x [Bp, D] = residual stream (token / latent embeddings); on return x holds the last layer's output, NOT normed
+  // Row statistics travel with the residual stream when all four layer GEMMs run on the LDS-DMA kernel (gemm_fused.hip): the kernel
+  // that writes x leaves per-tile sums of squares in `rowsq`, the RMSNorm prologue of the next kernel sums them.
+  bool stats_ok() {
+    const int D = h->D, F = h->F;
+    return h->gemm_lds && gemm_lds_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_lds_ok<T>(Bp, D, D, false, EPI_RESID) && gemm_lds_ok<T>(Bp, F, D, true, EPI_SWIGLU) &&
+           gemm_lds_ok<T>(Bp, D, F, false, EPI_RESID) && !h->splitk_inlaunch && D % 16 == 0;
+  }
+  bool x_has_stats = false;   // rowsq describes the current contents of x
+
   int layers_fused() {
     const int M = Bp, D = h->D, H = h->H, hd = h->hd, F = h->F;
     T* x = ln->x.as<T>();
     const size_t lstride = (size_t)Bp * H * S * hd;
+    const bool stats = stats_ok();
+    const int sq_stride = round_up(Bp, 64);
+    float* rowsq = ln->rowsq.as<float>();
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
       T* kc = ln->kcache.as<T>() + lstride * l;
@@ -532,6 +551,12 @@ struct Runner {
       fa.H = H;
       fa.hd = hd;
       fa.S = S;
+      fa.lds = h->gemm_lds;
+      if (stats && (l > 0 || x_has_stats)) {
+        fa.sq_in = rowsq;
+        fa.sq_tiles = D / 16;
+        fa.sq_stride = sq_stride;
+      }
       VLG_TRY(gemm_fused<T>(x, W<T>(p + "attention.wqkv.weight"), M, 3 * D, D, true, EPI_QKV, fa, st));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
@@ -542,19 +567,31 @@ struct Runner {
                            st, e0, e1, nullptr, 0, nullptr, attn_cnt(), row_pos));
       FusedGemm fr;
       fr.h = x;
+      fr.lds = h->gemm_lds;
       if (h->splitk_inlaunch) {   // measured r01: the release/acquire pair costs more than the idle CUs (22.9 s vs 22.6 s/step)
         fr.slabs = ln->ws.as<float>();
         fr.counters = ln->counters.as<int>();
         fr.max_tiles = kMaxTiles;
+      }
+      if (stats) {
+        fr.sq_out = rowsq;
+        fr.sq_stride = sq_stride;
       }
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
       fs.norm_w = W<T>(p + "ffn_norm.weight");
       fs.eps = h->cfg.norm_eps;
       fs.out = ln->g.as<T>();
+      fs.lds = h->gemm_lds;
+      if (stats) {
+        fs.sq_in = rowsq;
+        fs.sq_tiles = D / 16;
+        fs.sq_stride = sq_stride;
+      }
       VLG_TRY(gemm_fused<T>(x, W<T>(p + "feed_forward.w13"), M, F, D, true, EPI_SWIGLU, fs, st));
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
     }
+    x_has_stats = stats;
     return VLG_OK;
   }
 
@@ -564,6 +601,13 @@ struct Runner {
     FusedGemm fa;
     fa.norm_w = W<T>("norm.weight");
     fa.eps = h->cfg.norm_eps;
+    fa.lds = h->gemm_lds;
+    if (x_has_stats) {
+      fa.sq_in = ln->rowsq.as<float>();
+      fa.sq_tiles = D / 16;
+      fa.sq_stride = round_up(Bp, 64);
+    }
+    x_has_stats = false;
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       fa.out_f32 = ln->logits.as<float>();
       VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("output.weight"), Bp, h->V, D, true, EPI_STORE, fa, st));
@@ -767,6 +811,13 @@ struct Runner {
       VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
       FusedGemm f2;
       f2.out = ln->x.as<T>();
+      f2.lds = h->gemm_lds;
+      x_has_stats = false;
+      if (stats_ok() && fused_decode_ok() && gemm_lds_ok<T>(Bp, D, D, false, EPI_STORE)) {   // the first layer's norm finds its sums ready
+        f2.sq_out = ln->rowsq.as<float>();
+        f2.sq_stride = round_up(Bp, 64);
+        x_has_stats = true;
+      }
       VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
     } else if (h->cfg.model_type == VLG_T2V) {
       VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
@@ -880,6 +931,7 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
   if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
   VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
   VLG_TRY(ln.state.reserve(sizeof(StepState)));
+  VLG_TRY(ln.rowsq.reserve((size_t)(D / 16 + 1) * round_up(Bp, 64) * sizeof(float)));
   if (ln.counters.bytes == 0) {
     VLG_TRY(ln.counters.reserve(kMaxTiles * sizeof(int)));
     VLG_HIP(hipMemset(ln.counters.p, 0, kMaxTiles * sizeof(int)));
@@ -998,7 +1050,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->fuse_qkv ? 4 : 0) | (h->attn_inlaunch ? 8 : 0) |
-                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0))};
+                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0))};
       for (auto& r : rs) {
         key.push_back((uint64_t)(uintptr_t)r.st);
         const auto pk = r.ln->ptr_key();

@@ -49,6 +49,14 @@ struct FusedGemm {
   float* slabs = nullptr;
   int* counters = nullptr;
   int max_tiles = 0;
+  // Row statistics handed from the kernel that WRITES the residual stream to the PRO (RMSNorm) kernel that reads it next, so the
+  // consumer does not need its rows resident to normalise them: sq[t * sq_stride + row] = sum over the 16 columns of n-tile t of
+  // (stored value)^2.  sq_out: EPI_RESID / EPI_STORE producers (N / 16 tiles); sq_in: PRO consumers (sq_tiles = K / 16 partials per
+  // row, summed in tile order: deterministic).  sq_in == nullptr: the consumer computes the sums itself from x (one more pass).
+  float* sq_out = nullptr;
+  const float* sq_in = nullptr;
+  int sq_tiles = 0, sq_stride = 0;
+  bool lds = false;               // run on the LDS-DMA kernel (gemm_lds_kernel) where it covers the shape; off by default
 #ifdef VLG_KTRACE
   unsigned long long* trace = nullptr;   // tools/microbench only: 4 timestamps per workgroup
 #endif
@@ -57,6 +65,9 @@ template <typename T>
 bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
 template <typename T>
 int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st);
+// true if gemm_fused would run this shape on the LDS-DMA kernel (which is the one that honours sq_out / sq_in)
+template <typename T>
+bool gemm_lds_ok(int M, int N, int K, bool pro, int epi);
 
 // LayerNorm + adaLN-modulate prologue (DiffLoss ResBlock / FinalLayer, diffloss.py:55-56,120-128,141-148) fused into the skinny GEMM:
 //   out = rt(act(rt(bias + W . rt(rt(LN(x) [* ln_w + ln_b]) * (1 + scale[row]) + shift[row]))))
