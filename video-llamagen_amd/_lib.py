@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvlg.so")
+# VLG_LIB_PATH: load another build of the same library (tools/asan_host_check.sh points it at the host-AddressSanitizer build)
+LIB_PATH = os.environ.get("VLG_LIB_PATH") or os.path.join(_HERE, "lib", "libvlg.so")
 
 VLG_F32, VLG_BF16 = 0, 1
 VLG_C2I, VLG_T2I, VLG_T2V = 0, 1, 2
