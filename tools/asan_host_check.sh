@@ -22,4 +22,4 @@ echo "built $OUT/libvlg.so"
 cd "$ROOT"
 # detect_leaks=0: CPython itself "leaks" at exit; the checks of interest are out-of-bounds / use-after-free in the library's host code
 VLG_LIB_PATH="$OUT/libvlg.so" LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:protect_shadow_gap=0 \
-  python -m pytest tests/test_cabi_cpu.py tests/test_io_cpu.py tests/test_serve_cpu.py -x -q -p no:cacheprovider
+  python -m pytest tests/test_cabi_cpu.py tests/test_io_cpu.py tests/test_serve_cpu.py -x -q -p no:cacheprovider -m "not gpu"
