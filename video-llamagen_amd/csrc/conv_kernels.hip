@@ -777,10 +777,181 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const T* __restrict__
   for (int e = 0; e < EPL; ++e) DT<T>::st(out + qi * C + lane * EPL + e, acc[e] / l);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same attention on the matrix cores (bf16): the one place on this path where every key / value is reused by many queries
+// (HW queries per frame share the frame's K and V), so K and V are staged through LDS and both products run as 32x32x16 MFMAs.
+//
+// Workgroup = 4 waves = 32 query rows of one frame; wave w owns the channel slice [w C/4, (w+1) C/4).  Per block of 32 keys:
+//   1. K block -> LDS [32 keys][C] (16-byte chunks XOR-swizzled by key so the fragment reads are conflict-free), V block -> LDS
+//      TRANSPOSED [C][40] (keys contiguous per channel: the B operand of P.V wants 8 consecutive keys of one channel per lane);
+//   2. every wave: partial scores Q[:, slice] . K[:, slice]^T over its channel slice (C/64 MFMAs) -> LDS, summed over the 4 waves;
+//   3. online softmax of the 32 x 32 score block by all 256 threads (8 lanes per query row, running max / sum in registers),
+//      probabilities rounded to bf16 into LDS (the reference's bf16 path rounds its softmax output too, vq_model.py:343-346);
+//   4. every wave: O[:, slice] = O * alpha + P . V[:, slice]  (C/64 MFMAs), the P fragments read back from LDS as the A operand.
+// HW need not be a multiple of 32 (keys beyond HW are masked, rows beyond HW never stored).  fp32 handles keep the VALU kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void spatial_attn_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                                bf16* __restrict__ out, int HW, float scale) {
+  static_assert(C % 128 == 0, "four channel slices of whole 32-wide MFMA tiles");
+  constexpr int CW = C / 4;          // channels per wave
+  constexpr int KS = CW / 16;        // MFMA k-steps of the score product
+  constexpr int NTI = CW / 32;       // 32-channel output tiles per wave
+  constexpr int CH = C / 8;          // 16-byte chunks per key row
+  constexpr int VP = 40;             // padded key pitch of the transposed V block (bf16 elements; 80 B: conflict-free b128 reads)
+  extern __shared__ __attribute__((aligned(16))) char sa_smem[];
+  uint4* Ks = reinterpret_cast<uint4*>(sa_smem);                                   // [32][CH]
+  unsigned short* Vt = reinterpret_cast<unsigned short*>(sa_smem + 32 * C * 2);    // [C][VP]
+  float* Sp = reinterpret_cast<float*>(sa_smem + 32 * C * 2 + C * VP * 2);         // [4][32][33]
+  unsigned short* Pb = reinterpret_cast<unsigned short*>(Sp + 4 * 32 * 33);        // [32][VP]
+  float* al = reinterpret_cast<float*>(Pb + 32 * VP);                              // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int c0 = wave * CW;
+  const long long f = blockIdx.y;
+  const int q0 = blockIdx.x * 32;
+  const bf16* qf = q + f * HW * (long long)C;
+  const bf16* kf = k + f * HW * (long long)C;
+  const bf16* vf = v + f * HW * (long long)C;
+
+  // Q fragments (A operand): lane (row r32, half hh) holds channels c0 + 16 s + 8 hh .. + 7 of its query row
+  bf16x8_t qa[KS];
+  {
+    const int qr = (q0 + r32) < HW ? (q0 + r32) : HW - 1;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2)
+      qa[s2] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qf + (long long)qr * C + c0 + 16 * s2 + 8 * hh));
+  }
+  f32x16_t oacc[NTI];
+#pragma unroll
+  for (int n = 0; n < NTI; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[n][e] = 0.f;
+  // softmax roles: thread -> query row tid >> 3, key columns 4 (tid & 7) .. + 3; the row's running max / sum live in its 8 lanes
+  const int srow = tid >> 3, scg = tid & 7;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nblk = (HW + 31) / 32;
+  for (int kb = 0; kb < nblk; ++kb) {
+    // ---- 1. stage K (swizzled rows) and V (transposed) ----
+#pragma unroll
+    for (int i = 0; i < (32 * CH) / 256; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / CH, ch = e - row * CH;
+      int key = kb * 32 + row;
+      key = key < HW ? key : HW - 1;
+      const uint4 kv = *reinterpret_cast<const uint4*>(kf + (long long)key * C + ch * 8);
+      const uint4 vv = *reinterpret_cast<const uint4*>(vf + (long long)key * C + ch * 8);
+      Ks[row * CH + (ch ^ (row & 15))] = kv;
+      const unsigned short* ve = reinterpret_cast<const unsigned short*>(&vv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * VP + row] = ve[j];
+    }
+    __syncthreads();
+    // ---- 2. partial scores over this wave's channel slice ----
+    f32x16_t sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int chunk = c0 / 8 + 2 * s2 + hh;
+      const bf16x8_t kfrag = __builtin_bit_cast(bf16x8_t, Ks[r32 * CH + (chunk ^ (r32 & 15))]);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s2], kfrag, sacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Sp[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * 33 + r32] = sacc[e];
+    __syncthreads();
+    // ---- 3. online softmax of the 32 x 32 block ----
+    {
+      float sv[4], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 4 * scg + j;
+        const float t = Sp[(0 * 32 + srow) * 33 + col] + Sp[(1 * 32 + srow) * 33 + col] + Sp[(2 * 32 + srow) * 33 + col] + Sp[(3 * 32 + srow) * 33 + col];
+        sv[j] = (kb * 32 + col) < HW ? t * scale : -INFINITY;
+        mx = fmaxf(mx, sv[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = fmaxf(mx, __shfl_xor(mx, 2));
+      mx = fmaxf(mx, __shfl_xor(mx, 4));
+      const float mnew = fmaxf(m_run, mx);          // finite: the block holds at least one key < HW
+      const float alpha = __expf(m_run - mnew);      // 0 on the first block
+      float ps = 0.f;
+      unsigned short pb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pj = __expf(sv[j] - mnew);
+        ps += pj;
+        pb[j] = f32_to_bf16(pj);
+      }
+      ps += __shfl_xor(ps, 1);
+      ps += __shfl_xor(ps, 2);
+      ps += __shfl_xor(ps, 4);
+      l_run = l_run * alpha + ps;
+      m_run = mnew;
+      *reinterpret_cast<uint2*>(Pb + srow * VP + 4 * scg) = make_uint2((unsigned)pb[0] | ((unsigned)pb[1] << 16), (unsigned)pb[2] | ((unsigned)pb[3] << 16));
+      if (scg == 0) al[srow] = alpha;
+    }
+    __syncthreads();
+    // ---- 4. O = O * alpha + P . V over this wave's channel slice ----
+    {
+      float a16[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a16[e] = al[(e & 3) + 8 * (e >> 2) + 4 * hh];
+#pragma unroll
+      for (int n = 0; n < NTI; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[n][e] *= a16[e];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t pfrag = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Pb + r32 * VP + 16 * s2 + 8 * hh));
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+          const bf16x8_t vfrag = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Vt + (c0 + 32 * n + r32) * VP + 16 * s2 + 8 * hh));
+          oacc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfrag, vfrag, oacc[n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (scg == 0) al[srow] = 1.0f / l_run;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (q0 + row >= HW) continue;
+    const float inv = al[row];
+    bf16* op = out + (f * HW + q0 + row) * (long long)C + c0 + r32;
+#pragma unroll
+    for (int n = 0; n < NTI; ++n) op[32 * n].v = f32_to_bf16(oacc[n][e] * inv);
+  }
+}
+
+template <int C>
+static int spatial_attention_mfma(const bf16* q, const bf16* k, const bf16* v, bf16* out, int NF, int HW, float scale, hipStream_t st) {
+  const size_t lds = (size_t)32 * C * 2 + (size_t)C * 40 * 2 + (size_t)4 * 32 * 33 * 4 + (size_t)32 * 40 * 2 + 32 * 4;
+  static bool attr = false;
+  if (!attr) {
+    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spatial_attn_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  spatial_attn_mfma_kernel<C><<<dim3((unsigned)cdiv(HW, 32), (unsigned)NF), 256, lds, st>>>(q, k, v, out, HW, scale);
+  return VLG_OK;
+}
+
 template <typename T>
 int spatial_attention(const T* q, const T* k, const T* v, T* out, int NF, int HW, int C, hipStream_t st) {
   const long long nq = (long long)NF * HW;
   const float scale = 1.0f / sqrtf((float)C);   // int(c) ** (-0.5)
+  if constexpr (sizeof(T) == 2) {
+    static const bool mfma_off = getenv("VLG_ATTN_MFMA") != nullptr && atoi(getenv("VLG_ATTN_MFMA")) == 0;   // A/B knob
+    if (!mfma_off) {
+      if (C == 512) return spatial_attention_mfma<512>(q, k, v, out, NF, HW, scale, st);
+      if (C == 256) return spatial_attention_mfma<256>(q, k, v, out, NF, HW, scale, st);
+      if (C == 128) return spatial_attention_mfma<128>(q, k, v, out, NF, HW, scale, st);
+    }
+  }
   dim3 grid((unsigned)cdiv64(nq, 4));
   if (C == 512)
     spatial_attn_kernel<T, 8><<<grid, 256, 0, st>>>(q, k, v, out, nq, HW, C, scale);
