@@ -103,11 +103,17 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
  * of max_new_tokens + 1 positions; with sp->cfg_scale > 1 every slot carries its unconditional partner internally.
  *   session_step  advances EVERY slot by one token, each slot at its own position.  h_row_class[rows] (host memory):
  *                 >= 0  start a request with this class id in the slot (its first token is sampled by this step),
+ *                 -3    (text-conditioned models) start the request whose condition vlg_gpt_session_prefill put into the slot,
  *                 -1    continue the slot's request,   -2  leave the slot idle.
  *                 The call returns after the step has run; tokens stay on the device.
  *   session_read  copies the first n_tokens tokens of a slot to host memory (call it when the request is done, before
  *                 the slot is reused).                                                                               */
 int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp);
+/* Text-conditioned token models (t2i): puts ONE request's condition into a slot (ending whatever ran there) - d_cond fp32 [cls_token_num, caption_dim]
+ * (already * mask, sample_t2i.py:105-119), d_mask fp32 [cls_token_num] (1 = valid, left-padded) or NULL.  Positions 0 .. T-2 are
+ * prefilled into the slot's KV rows (and uncond_embedding into its guidance partner's); the request then starts with code -3 in
+ * session_step, whose first iteration runs the last condition token at position T-1 and samples token 0.  Waits for the prefill. */
+int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask);
 int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class);
 int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out);
 int vlg_gpt_session_end(vlg_gpt_t* h);

@@ -168,6 +168,39 @@ def test_session_engines_vs_reference_golden(golden):
     assert (run(V.LLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=6), True) == g["c2i_fp32_cfg_ids"]).all()
 
 
+def test_t2i_sessions_vs_reference_golden(golden):
+    """Text-conditioned requests through the iteration-level engine (vlg_gpt_session_prefill + session_step): each request's 120-token
+    condition is prefilled into its slot, then it joins the running batch.  Ids equal the REFERENCE's generate() on the same captions
+    (tests/golden/gpt.npz, TINY_T2I fp32 greedy; ragged left-padded masks 120 / 3 / 57 valid tokens), without guidance and with
+    guidance 2.5 / cfg_interval 6, with as many slots as requests and with fewer (the third request starts in a reused slot while
+    the first two are mid-flight)."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    g = golden("gpt")
+    cfg = cases.TINY_T2I
+    m, _ = product_gpt(cfg, torch.float32)
+    c, mk = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[120, 3, 57])
+    N = cfg["block_size"]
+    sp = V.SamplingParams(temperature=0.0, max_tokens=N)
+
+    def run(engine):
+        for i in range(3):
+            engine.add_request(str(i), None, sp, prompt_embeds=torch.from_numpy(c[i]), emb_mask=torch.from_numpy(mk[i]))
+        outs = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+        return np.array([outs[i] for i in range(3)])
+
+    for slots in (3, 2):
+        assert (run(V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=slots)) == g["t2i_fp32_greedy_ids"]).all(), slots
+        assert (run(V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=slots)) == g["t2i_fp32_cfg_ids"]).all(), slots
+    eng = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=2)
+    with pytest.raises(ValueError):
+        eng.add_request("x", None, sp, prompt_token_ids=[3])           # a text-conditioned engine takes features, not class ids
+
+
 def test_session_and_t5_error_paths():
     """Loud failures instead of silent fallbacks: sessions on a text-conditioned model, stepping without a session, slot overrun,
     T5 configurations / sequence lengths that are not built."""
@@ -177,9 +210,16 @@ def test_session_and_t5_error_paths():
     from oracle import cases
     from vlg_testutil import product_gpt
     sp = L.SamplingParams(cfg_scale=1.0, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=0, seed=0)
+    t2v, _ = product_gpt(cases.TINY_T2V, torch.float32)
+    with pytest.raises(L.VlgError, match="token models"):
+        L.check(L.lib().vlg_gpt_session_begin(t2v._handle, 2, 4, C.byref(sp)))
     t2i, _ = product_gpt(cases.TINY_T2I, torch.float32)
-    with pytest.raises(L.VlgError, match="class-conditional"):
-        L.check(L.lib().vlg_gpt_session_begin(t2i._handle, 2, 4, C.byref(sp)))
+    L.check(L.lib().vlg_gpt_session_begin(t2i._handle, 2, 4, C.byref(sp)))
+    with pytest.raises(L.VlgError, match="no prefilled condition"):
+        L.check(L.lib().vlg_gpt_session_step(t2i._handle, (C.c_int32 * 2)(-3, -2)))
+    with pytest.raises(L.VlgError, match="does not fit"):
+        L.check(L.lib().vlg_gpt_session_step(t2i._handle, (C.c_int32 * 2)(5, -2)))
+    L.check(L.lib().vlg_gpt_session_end(t2i._handle))
     c2i, _ = product_gpt(cases.TINY_C2I, torch.float32)
     rows = (C.c_int32 * 2)(1, -2)
     with pytest.raises(L.VlgError, match="no open session"):
@@ -187,6 +227,8 @@ def test_session_and_t5_error_paths():
     with pytest.raises(L.VlgError, match="RoPE table"):
         L.check(L.lib().vlg_gpt_session_begin(c2i._handle, 2, 17, C.byref(sp)))
     L.check(L.lib().vlg_gpt_session_begin(c2i._handle, 2, 3, C.byref(sp)))
+    with pytest.raises(L.VlgError, match="text-conditioned"):
+        L.check(L.lib().vlg_gpt_session_prefill(c2i._handle, 0, L.ptr(torch.zeros(1, device="cuda")), None))
     L.check(L.lib().vlg_gpt_session_step(c2i._handle, rows))
     cont = (C.c_int32 * 2)(-1, -2)
     L.check(L.lib().vlg_gpt_session_step(c2i._handle, cont))

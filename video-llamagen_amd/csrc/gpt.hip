@@ -456,6 +456,10 @@ struct Runner {
   int ev_slot = -1;    // >= 0: bracket layer 0's attention kernel with attn_ev[2*slot], [2*slot+1]
   const int32_t* row_pos = nullptr;    // sessions: per-row positions / token indices (device arrays); null = uniform StepState
   const int32_t* row_step = nullptr;
+  int kv_row0 = 0, kv_rows = 0;        // this runner's rows are rows kv_row0.. of a cache holding kv_rows batch rows (0 = Bp): slot prefill
+  const void* pending = nullptr;       // sessions of text-conditioned models: [rows][D] input rows of slots that start this step
+  size_t kv_lstride() const { return (size_t)(kv_rows ? kv_rows : Bp) * h->H * S * h->hd; }
+  size_t kv_off() const { return (size_t)kv_row0 * h->H * S * h->hd; }
   StepState* state() { return ln->state.as<StepState>(); }
   int* attn_cnt() { return h->attn_inlaunch ? ln->attn_cnt.as<int>() : nullptr; }
   template <typename U>
@@ -475,13 +479,13 @@ struct Runner {
     T* x = ln->x.as<T>();
     T* xn = ln->xn.as<T>();
     float* ws = ln->ws.as<float>();
-    const size_t lstride = (size_t)Bp * H * S * hd;
+    const size_t lstride = kv_lstride();
     VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, W<T>("layers.0.attention_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
       int sp = 1;
-      T* kc = ln->kcache.as<T>() + lstride * l;
-      T* vc = ln->vcache.as<T>() + lstride * l;
+      T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
+      T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
       const bool fused = (Tq == 1) && h->fuse_qkv;
       if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos));
@@ -530,14 +534,14 @@ struct Runner {
   int layers_fused() {
     const int M = Bp, D = h->D, H = h->H, hd = h->hd, F = h->F;
     T* x = ln->x.as<T>();
-    const size_t lstride = (size_t)Bp * H * S * hd;
+    const size_t lstride = kv_lstride();
     const bool stats = stats_ok();
     const int sq_stride = round_up(Bp, 64);
     float* rowsq = ln->rowsq.as<float>();
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
-      T* kc = ln->kcache.as<T>() + lstride * l;
-      T* vc = ln->vcache.as<T>() + lstride * l;
+      T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
+      T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
       FusedGemm fa;
       fa.norm_w = W<T>(p + "attention_norm.weight");
       fa.eps = h->cfg.norm_eps;
@@ -839,8 +843,9 @@ struct Runner {
   // one iteration of the request scheduler: every row at its own position (StepState::row_pos / row_step), inputs per row_cls
   int session_step(const vlg_sampling_params& sp, const int32_t* row_cls, int32_t* out_ids) {
     const int D = h->D;
-    VLG_TRY(gather_session_rows<T>(W<T>("cls_embedding.embedding_table.weight"), h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V,
-                                   row_cls, ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, st));
+    const T* cls_table = h->cfg.model_type == VLG_C2I ? W<T>("cls_embedding.embedding_table.weight") : nullptr;
+    VLG_TRY(gather_session_rows<T>(cls_table, h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V, row_cls, ln->cur_tok.as<int32_t>(),
+                                   reinterpret_cast<const T*>(pending), ln->x.as<T>(), Bp, D, st));
     if (fused_decode_ok()) {
       VLG_TRY(layers_fused());
       return head_fused(sp, nullptr, out_ids, nullptr, nullptr);
@@ -1134,6 +1139,8 @@ struct vlg_gpt::Session {
   bool cfg = false;
   vlg_sampling_params sp{};
   DevBuf row_pos, row_step, row_cls, out_ids;
+  DevBuf maskbuf, pending;            // text-conditioned models: [R][Tc] fp32 condition masks; [Rp][D] input rows of starting slots
+  std::vector<char> prefilled;        // slot has a condition in its KV rows and waits for its first step
   std::vector<int32_t> pos;           // host mirror: -1 = idle, else input position of the slot's next step
   std::vector<int32_t> h_pos, h_step, h_cls;
   hipGraph_t graph = nullptr;
@@ -1165,14 +1172,24 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   VLG_HIP(hipMemset(ses->ln.cur_tok.p, 0, (size_t)ses->Rp * sizeof(int32_t)));
   VLG_HIP(hipMemset(ses->out_ids.p, 0, (size_t)R * maxN * sizeof(int32_t)));
   ses->pos.assign(R, -1);
+  ses->prefilled.assign(R, 0);
   ses->h_pos.assign(ses->Rp, 0);
   ses->h_step.assign(ses->Rp, 0);
-  ses->h_cls.assign(ses->Rp, h->cfg.num_classes);
+  const bool text = h->cfg.model_type != VLG_C2I;
+  ses->h_cls.assign(ses->Rp, text ? -3 : h->cfg.num_classes);
   hipStream_t st = ses->ln.st;
+  if (text) {   // every slot starts with an all-valid mask and a zero input row (idle slots park on it)
+    VLG_TRY(ses->maskbuf.reserve((size_t)R * h->Tc * sizeof(float)));
+    VLG_TRY(ses->pending.reserve((size_t)ses->Rp * h->D * sizeof(T)));
+    std::vector<float> ones((size_t)R * h->Tc, 1.0f);
+    VLG_HIP(hipMemcpy(ses->maskbuf.p, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+    VLG_HIP(hipMemset(ses->pending.p, 0, (size_t)ses->Rp * h->D * sizeof(T)));
+  }
   VLG_TRY(set_state(ses->ln.state.as<StepState>(), 0, 0, st));
-  Runner<T> r{h, &ses->ln, st, R, ses->Rp, maxN, ses->S, 0, R, nullptr};
+  Runner<T> r{h, &ses->ln, st, R, ses->Rp, maxN, ses->S, 0, R, text ? ses->maskbuf.as<float>() : nullptr};
   r.row_pos = ses->row_pos.as<int32_t>();
   r.row_step = ses->row_step.as<int32_t>();
+  r.pending = ses->pending.p;
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1190,28 +1207,39 @@ template <typename T>
 int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   vlg_gpt::Session& s = *h->ses;
   const int R = s.R, null_cls = h->cfg.num_classes;
+  const bool text = h->cfg.model_type != VLG_C2I;
+  const int first = h->Tc - 1;         // input position of the step that samples token 0 (the last condition token)
   for (int b = 0; b < R; ++b) {
     const int c = h_row_class[b];
-    int cls = -1;
-    if (c >= 0) {                      // start a request in this slot
+    int cls = -1, cls_partner = -1;
+    if (c >= 0 && !text) {             // start a class-conditional request in this slot
       VLG_CHECK(c <= null_cls, VLG_ERR_BAD_ARG, "class id %d out of range", c);
       s.pos[b] = 0;
       cls = c;
+      cls_partner = null_cls;          // unconditional partner row: null class at the start (generate.py:131)
+    } else if (c == -3 && text) {      // start the request whose condition vlg_gpt_session_prefill put into this slot
+      VLG_CHECK(s.prefilled[b], VLG_ERR_STATE, "slot %d has no prefilled condition", b);
+      s.prefilled[b] = 0;
+      s.pos[b] = first;
+      cls = cls_partner = -3;          // input row = the projected last condition token (cond / uncond), left in `pending`
     } else if (c == -1 && s.pos[b] >= 0) {   // continue
       s.pos[b] += 1;
-      VLG_CHECK(s.pos[b] < s.maxN, VLG_ERR_BAD_SHAPE, "slot %d stepped past max_new_tokens %d", b, s.maxN);
-    } else {                           // idle (or told to stop): park the slot at position 0 on the null class
+      VLG_CHECK(s.pos[b] < first + s.maxN, VLG_ERR_BAD_SHAPE, "slot %d stepped past max_new_tokens %d", b, s.maxN);
+    } else {                           // idle (or told to stop): park the slot at position 0 on the null class / a zero row
+      VLG_CHECK(c < 0, VLG_ERR_BAD_ARG, "slot %d: start code %d does not fit this model type", b, c);
       s.pos[b] = -1;
-      cls = null_cls;
+      cls = cls_partner = text ? -3 : null_cls;
+      if (text && s.prefilled[b]) cls = cls_partner = -1;   // do not step on a waiting slot's KV row 0: feed a token row at ITS position
     }
-    const int p = s.pos[b] < 0 ? 0 : s.pos[b];
+    int p = s.pos[b] < 0 ? 0 : s.pos[b];
+    if (text && s.pos[b] < 0 && s.prefilled[b]) p = first;  // a prefilled, not yet started slot idles at its first position
     s.h_pos[b] = p;
-    s.h_step[b] = p;                   // c2i: one condition token, so token index == input position
+    s.h_step[b] = p >= first ? p - first : 0;   // token index
     s.h_cls[b] = cls;
-    if (s.cfg) {                       // unconditional partner row: same position, null class at the start (generate.py:131)
+    if (s.cfg) {
       s.h_pos[b + R] = p;
-      s.h_step[b + R] = p;
-      s.h_cls[b + R] = cls >= 0 ? null_cls : -1;
+      s.h_step[b + R] = s.h_step[b];
+      s.h_cls[b + R] = cls_partner;
     }
   }
   hipStream_t st = s.ln.st;
@@ -1222,9 +1250,10 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   if (s.exec) {
     VLG_HIP(hipGraphLaunch(s.exec, st));
   } else {
-    Runner<T> r{h, &s.ln, st, R, s.Rp, s.maxN, s.S, 0, R, nullptr};
+    Runner<T> r{h, &s.ln, st, R, s.Rp, s.maxN, s.S, 0, R, text ? s.maskbuf.as<float>() : nullptr};
     r.row_pos = s.row_pos.as<int32_t>();
     r.row_step = s.row_step.as<int32_t>();
+    r.pending = s.pending.p;
     VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>()));
   }
   // the host arrays are reused by the next call: the copies above must have been consumed
@@ -1233,10 +1262,56 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
 }
 }  // namespace
 
+namespace {
+// Condition of ONE request into the KV rows of its slot (and of its unconditional partner under guidance): positions 0 .. Tc-2 run
+// through the prefill kernels (slab GEMMs, masked causal attention) against the slot's cache rows; the projected LAST condition token
+// is kept as the slot's pending input row, so the step that samples token 0 is an ordinary iteration of the batch at position Tc-1.
+template <typename T>
+int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float* d_mask) {
+  vlg_gpt::Session& s = *h->ses;
+  const int Tc = h->Tc, D = h->D, cd = h->cd;
+  hipStream_t st = s.ln.st;
+  float* mrow = s.maskbuf.as<float>() + (size_t)slot * Tc;
+  if (d_mask) {
+    VLG_HIP(hipMemcpyAsync(mrow, d_mask, (size_t)Tc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    std::vector<float> ones((size_t)Tc, 1.0f);
+    VLG_HIP(hipMemcpyAsync(mrow, ones.data(), (size_t)Tc * sizeof(float), hipMemcpyHostToDevice, st));
+    VLG_HIP(hipStreamSynchronize(st));
+  }
+  for (int pass = 0; pass < (s.cfg ? 2 : 1); ++pass) {
+    Runner<T> r{h, &s.ln, st, 1, 1, s.maxN, s.S, 0, 1, mrow};
+    r.kv_row0 = slot + pass * s.R;
+    r.kv_rows = s.Rp;
+    VLG_TRY(set_state(r.state(), 0, 0, st));
+    // pass 0: the request's caption features; pass 1: uncond_embedding (generate.py:138-139)
+    VLG_TRY(build_text_cond<T>(d_cond, r.template W<T>("cls_embedding.uncond_embedding"), s.ln.condT.as<T>(), pass == 0 ? 1 : 0, 1, Tc, cd, st));
+    VLG_TRY(r.linear(s.ln.condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", s.ln.t1.as<T>(), nullptr, Tc, D, cd, ACT_GELU_TANH));
+    VLG_TRY(r.linear(s.ln.t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", s.ln.x.as<T>(), nullptr, Tc, D, D, ACT_NONE));
+    VLG_TRY(take_last_rows<T>(s.ln.x.as<T>(), s.pending.as<T>() + (size_t)r.kv_row0 * D, 1, Tc, D, st));
+    if (Tc > 1) VLG_TRY(r.layers(Tc - 1, Tc - 2));
+  }
+  VLG_HIP(hipStreamSynchronize(st));
+  s.prefilled[slot] = 1;
+  return VLG_OK;
+}
+}  // namespace
+
+extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask) {
+  VLG_CHECK(h && d_cond, VLG_ERR_BAD_ARG, "vlg_gpt_session_prefill: null argument");
+  VLG_CHECK(h->ses != nullptr, VLG_ERR_STATE, "no open session");
+  VLG_CHECK(h->cfg.model_type == VLG_T2I, VLG_ERR_UNSUPPORTED, "vlg_gpt_session_prefill is for text-conditioned token models");
+  VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
+  h->ses->pos[slot] = -1;   // whatever ran in the slot is over: the caller reuses it (its tokens were read with session_read)
+  return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
+}
+
 extern "C" int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp) {
   VLG_CHECK(h && sp && rows > 0 && max_new_tokens > 0, VLG_ERR_BAD_ARG, "vlg_gpt_session_begin: bad argument");
-  VLG_CHECK(h->cfg.model_type == VLG_C2I && h->cfg.head == VLG_HEAD_LOGITS, VLG_ERR_UNSUPPORTED,
-            "sessions cover class-conditional token models (the reference's serving path, serve/sample_c2i.py)");
+  VLG_CHECK(h->cfg.head == VLG_HEAD_LOGITS && (h->cfg.model_type == VLG_C2I || h->cfg.model_type == VLG_T2I), VLG_ERR_UNSUPPORTED,
+            "sessions cover the token models: class-conditional (serve/sample_c2i.py) and text-conditioned");
+  if (sp->cfg_scale > 1.0f && h->cfg.model_type == VLG_T2I)
+    VLG_CHECK(h->Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
   VLG_CHECK(h->Tc + max_new_tokens <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table", max_new_tokens);
   for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
   h->ses.reset();

@@ -1211,12 +1211,15 @@ template int latent_out_fc2<bf16>(const bf16*, const bf16*, float*, float*, floa
 template <typename T>
 __global__ __launch_bounds__(256) void gather_session_rows_kernel(const T* __restrict__ cls_table, int n_cls, const T* __restrict__ tok_table,
                                                                   int n_tok, const int32_t* __restrict__ row_cls,
-                                                                  const int32_t* __restrict__ cur_tok, T* __restrict__ out, int D) {
+                                                                  const int32_t* __restrict__ cur_tok, const T* __restrict__ pending,
+                                                                  T* __restrict__ out, int D) {
   const int m = blockIdx.x;
   const int c = row_cls[m];
   const T* src;
-  if (c >= 0) {
+  if (c >= 0 && cls_table != nullptr) {
     src = cls_table + (size_t)(c < n_cls ? c : n_cls - 1) * D;
+  } else if (c == -3 || (c >= 0 && cls_table == nullptr)) {
+    src = pending + (size_t)m * D;   // text-conditioned slot: the projected last condition token left by the slot's prefill
   } else {
     int tk = cur_tok[m];
     tk = tk < 0 ? 0 : (tk >= n_tok ? n_tok - 1 : tk);
@@ -1225,13 +1228,14 @@ __global__ __launch_bounds__(256) void gather_session_rows_kernel(const T* __res
   for (int i = threadIdx.x; i < D; i += 256) out[(size_t)m * D + i] = src[i];
 }
 template <typename T>
-int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok, T* out,
-                        int rows, int D, hipStream_t st) {
-  gather_session_rows_kernel<T><<<rows, 256, 0, st>>>(cls_table, n_cls, tok_table, n_tok, row_cls, cur_tok, out, D);
+int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok,
+                        const T* pending, T* out, int rows, int D, hipStream_t st) {
+  gather_session_rows_kernel<T><<<rows, 256, 0, st>>>(cls_table, n_cls, tok_table, n_tok, row_cls, cur_tok, pending, out, D);
   return VLG_OK;
 }
-template int gather_session_rows<float>(const float*, int, const float*, int, const int32_t*, const int32_t*, float*, int, int, hipStream_t);
-template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, bf16*, int, int, hipStream_t);
+template int gather_session_rows<float>(const float*, int, const float*, int, const int32_t*, const int32_t*, const float*, float*, int, int,
+                                        hipStream_t);
+template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, const bf16*, bf16*, int, int, hipStream_t);
 
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;

@@ -78,6 +78,8 @@ class _Request:
     prompt_token_ids: List[int]
     params: SamplingParams
     arrival: float
+    prompt_embeds: Optional[torch.Tensor] = None     # text-conditioned models: [cls_token_num, caption_dim] features (already * mask)
+    emb_mask: Optional[torch.Tensor] = None          # [cls_token_num], 1 = valid, left-padded
 
 
 class Scheduler:
@@ -185,7 +187,8 @@ class ContinuousLLMEngine:
         self.cfg_scale, self.cfg_interval, self.seed = float(cfg_scale), cfg_interval, seed
         self.cfg = self.cfg_scale > 1.0
         self.null_token = model.num_classes
-        self.slots_n = max(1, max_num_seqs // 2 if self.cfg else max_num_seqs)
+        self.text = model.model_type == "t2i"         # conditions are caption features: prefilled per slot, guidance partner internal
+        self.slots_n = max(1, max_num_seqs // 2 if (self.cfg and not self.text) else max_num_seqs)
         self.max_tokens = max_tokens
         self.waiting = collections.deque()
         self.pending_null = collections.deque()      # null-class partner requests (reported with their partner's tokens)
@@ -194,7 +197,17 @@ class ContinuousLLMEngine:
         self._params = None
         self.steps_run = 0
 
-    def add_request(self, request_id, prompt, sampling_params, prompt_token_ids=None, **_):
+    def add_request(self, request_id, prompt, sampling_params, prompt_token_ids=None, prompt_embeds=None, emb_mask=None, **_):
+        if self.text:
+            # text-conditioned request: T5 features [cls_token_num, caption_dim] (* mask) + left-padded mask, as sample_t2i.py:105-119
+            # builds them; under guidance the unconditional partner (uncond_embedding, generate.py:138) lives inside the slot
+            if prompt_embeds is None:
+                raise ValueError("text-conditioned requests carry prompt_embeds [cls_token_num, caption_dim]")
+            want = (self.model.cls_token_num, self.model.config.caption_dim)
+            if tuple(prompt_embeds.shape) != want:
+                raise ValueError("prompt_embeds must be %s, got %s" % (want, tuple(prompt_embeds.shape)))
+            self.waiting.append(_Request(str(request_id), [], sampling_params or SamplingParams(), time.time(), prompt_embeds, emb_mask))
+            return
         if prompt_token_ids is None or len(prompt_token_ids) != 1:
             raise ValueError("class-conditional prompts hold exactly one class id")
         r = _Request(str(request_id), list(prompt_token_ids), sampling_params or SamplingParams(), time.time())
@@ -241,6 +254,17 @@ class ContinuousLLMEngine:
                 r = self.waiting[0]
                 if r.params.max_tokens > self.session_tokens:
                     raise ValueError("request %s asks for %d tokens, the session holds %d" % (r.request_id, r.params.max_tokens, self.session_tokens))
+                if self.text:
+                    self.waiting.popleft()
+                    dev = self.model._device
+                    emb = r.prompt_embeds.to(device=dev, dtype=torch.float32).contiguous()
+                    msk = None if r.emb_mask is None else r.emb_mask.to(device=dev, dtype=torch.float32).contiguous()
+                    with torch.cuda.device(dev):
+                        torch.cuda.current_stream(dev).synchronize()        # the features may come from another stream's work
+                        L.check(L.lib().vlg_gpt_session_prefill(self.model._handle, i, L.ptr(emb), L.ptr(msk)))
+                    self.slots[i] = [r, 0, None]
+                    row_class[i] = -3                               # first iteration: the last condition token, samples token 0
+                    continue
                 if self.cfg and not self.pending_null:
                     continue                                        # its null-class partner has not arrived yet
                 self.waiting.popleft()
