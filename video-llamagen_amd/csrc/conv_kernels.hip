@@ -57,10 +57,17 @@ __device__ __forceinline__ long long tap_src(const PosDec& pd, const ConvDesc& d
   return ((((long long)pd.b * d.Ti + ti) * d.Hi + iy) * d.Wi + ix) * d.Cin;
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* __restrict__ in, const bf16* __restrict__ w,
-                                                        const float* __restrict__ bias, const bf16* __restrict__ residual,
-                                                        bf16* __restrict__ out_cl, float* __restrict__ out_planar) {
+// T = bf16: 32-channel K steps on v_mfma_f32_32x32x16_bf16.  T = float (round 2; the reference runs the VQ-16 decoder in fp32): 16-channel
+// K steps - the same 64-byte LDS rows - on the exact-fp32 v_mfma_f32_32x32x2_f32, so the 1x1 convolutions of the attention blocks, the
+// shortcut convolutions and conv_out (Cout 3) of an fp32 handle no longer run the direct-convolution kernel (69 % of an fp32 decode).
+// SMALLC: Cin below one K step (post_quant_conv: 8 -> 4, CausalVAE conv_in: 4 -> 512): one zero-padded K step per tap, operands gathered
+// element by element - tiny layers, but they no longer fall to the direct-convolution kernel.
+template <typename T, int BN, bool SMALLC = false>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+                                                        const float* __restrict__ bias, const T* __restrict__ residual,
+                                                        T* __restrict__ out_cl, float* __restrict__ out_planar) {
+  constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int KC = 4 * EPV;                // channels per K step
   constexpr int BM = 128;
   constexpr int WM = (BN == 128) ? 64 : 32, WN = (BN == 128) ? 64 : 32;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* 
   const long long pos0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int taps = d.kt * d.kh * d.kw;
-  const int ncc = d.Cin / 32;
+  const int ncc = SMALLC ? 1 : d.Cin / KC;
   const int nk = taps * ncc;
 
   // loader roles
@@ -103,17 +110,40 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* 
     const int tap = ks / ncc, cc = ks - tap * ncc;
     const int a = tap / (d.kh * d.kw), rem = tap - a * (d.kh * d.kw);
     const int ii = rem / d.kw, jj = rem - ii * d.kw;
+    if constexpr (SMALLC) {
+      auto gather = [&](const T* base, bool ok, int chunk) {
+        alignas(16) T tmp[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const int c = chunk * EPV + e;
+          DT<T>::st(&tmp[e], (ok && c < d.Cin) ? DT<T>::ld(base + c) : 0.f);
+        }
+        return *reinterpret_cast<const uint4*>(tmp);
+      };
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long long src = tap_src(pd[i], d, a, ii, jj);
+        ra[i] = gather(in + (src >= 0 ? src : 0), src >= 0, ach[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NBL; ++i) {
+        const int co = n0 + brow[i];
+        const bool ok = bok[i] && co < d.Cout;
+        rb[i] = gather(w + ((size_t)(ok ? co : 0) * taps + tap) * d.Cin, ok, bch[i]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long long src = tap_src(pd[i], d, a, ii, jj);
       ra[i] = make_uint4(0, 0, 0, 0);
-      if (src >= 0) ra[i] = *reinterpret_cast<const uint4*>(in + src + cc * 32 + ach[i] * 8);
+      if (src >= 0) ra[i] = *reinterpret_cast<const uint4*>(in + src + cc * KC + ach[i] * EPV);
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
       rb[i] = make_uint4(0, 0, 0, 0);
       const int co = n0 + brow[i];
-      if (bok[i] && co < d.Cout) rb[i] = *reinterpret_cast<const uint4*>(w + ((size_t)co * taps + tap) * d.Cin + cc * 32 + bch[i] * 8);
+      if (bok[i] && co < d.Cout) rb[i] = *reinterpret_cast<const uint4*>(w + ((size_t)co * taps + tap) * d.Cin + cc * KC + bch[i] * EPV);
     }
   };
   auto lstore = [&](int buf) {
@@ -141,21 +171,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* 
     if (ks + 1 < nk) gload(ks + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[MI], bfr[NI];
+      uint4 af[MI], bfr[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wave_m * WM + mi * 32 + r32;
-        af[mi] = __builtin_bit_cast(bf16x8_t, As[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+        af[mi] = As[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int row = wave_n * WN + ni * 32 + r32;
-        bfr[ni] = __builtin_bit_cast(bf16x8_t, Bs[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))]);
+        bfr[ni] = Bs[buf][row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
       }
+      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]),
+                                                                  acc[mi][ni], 0, 0, 0);
+      } else {
+        // K = 2 per MFMA: element e of the hh = 0 lanes' chunk pairs with element e of the hh = 1 lanes' chunk (as in conv_halo_kernel<float>)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&af[mi].x)[e]), __uint_as_float((&bfr[ni].x)[e]), acc[mi][ni],
+                                                                 0, 0, 0);
+      }
     }
     if (ks + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -175,9 +219,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const bf16* 
         const long long p = pos0 + prow;
         if (p < ptot && co < d.Cout) {
           float v = acc[mi][ni][e] + bv;
-          if (residual) v += bf16_to_f32(residual[p * d.Cout + co].v);
+          if (residual) v += DT<T>::ld(residual + p * d.Cout + co);
           if (out_cl)
-            out_cl[p * d.Cout + co].v = f32_to_bf16(v);
+            DT<T>::st(out_cl + p * d.Cout + co, v);
           else
             out_planar[((p / pper) * d.Cout + co) * pper + (p % pper)] = v;
         }
@@ -565,17 +609,24 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       return VLG_OK;
     }
   }
-  if constexpr (sizeof(T) == 2) {
-    if (d.Cin % 32 == 0) {
-      const bool wide = (d.Cout % 128 == 0);
-      const int bn = wide ? 128 : 32;
-      dim3 grid((unsigned)cdiv64(ptot, 128), (unsigned)cdiv(d.Cout, bn));
-      if (wide)
-        conv_mfma_kernel<128><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-      else
-        conv_mfma_kernel<32><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-      return VLG_OK;
-    }
+  if (d.Cin % (64 / (int)sizeof(T)) == 0) {   // whole 64-byte K steps: 32 bf16 / 16 fp32 channels
+    const bool wide = (d.Cout % 128 == 0);
+    const int bn = wide ? 128 : 32;
+    dim3 grid((unsigned)cdiv64(ptot, 128), (unsigned)cdiv(d.Cout, bn));
+    if (wide)
+      conv_mfma_kernel<T, 128><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+    else
+      conv_mfma_kernel<T, 32><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+    return VLG_OK;
+  }
+  if (d.Cin < 64 / (int)sizeof(T)) {          // fewer channels than one K step: zero-padded K step per tap
+    const bool wide = (d.Cout % 128 == 0);
+    dim3 grid((unsigned)cdiv64(ptot, 128), (unsigned)cdiv(d.Cout, wide ? 128 : 32));
+    if (wide)
+      conv_mfma_kernel<T, 128, true><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+    else
+      conv_mfma_kernel<T, 32, true><<<grid, 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+    return VLG_OK;
   }
   const long long total = ptot * d.Cout;
   conv_naive_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
