@@ -439,6 +439,83 @@ def test_diffloss_head_bf16_and_100_steps():
     assert np.abs(lat[:, 0] - ref[:, 0]).max() < 8e-2 * max(1.0, np.abs(ref[:, 0]).max())
 
 
+def _diff_model_w(dtype, width, steps):
+    cfg = dict(cases.TINY_T2V_DIFF, num_sampling_steps=steps, diffloss_w=width)
+    import video_llamagen_amd as V
+    keys = ("dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "caption_dim", "vae_embed_dim",
+            "num_frames", "t_downsample_size", "head", "diffloss_w", "diffloss_d", "num_sampling_steps")
+    m = V.Transformer(V.ModelArgs(**{k: cfg[k] for k in keys})).to("cuda", dtype).eval()
+    sd = detweights.gpt_weights(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m, cfg, sd
+
+
+@pytest.mark.parametrize("B", [1, 6])
+def test_diffloss_persistent_sampler_vs_oracle_and_launch_chain(B):
+    """The one-launch sampler (csrc/diffloss_persist.hip: workgroups of a 4-row group all-gather activations through global memory)
+    against the oracle and against the per-step launch chain.  Width 256 is the smallest the persistent kernel covers (8 column
+    tiles per group); 6 rows = one full group + one ragged group."""
+    import video_llamagen_amd as V
+    m, cfg, sd = _diff_model_w(torch.float32, 256, 10)
+    C, N, S = cfg["vae_embed_dim"], 5, 10
+    noise = cases.rng(61).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4][:B])
+    om = O.GPTOracle(cfg, sd, "fp32")
+    ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.95)
+    out = {}
+    for persist in (True, False):
+        m.dl_persist = persist
+        lat, tr = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.95, noise=torch.from_numpy(noise),
+                                 return_trace=True)
+        out[persist] = to_np(lat)
+        assert np.isfinite(out[persist]).all(), persist
+        assert np.abs(out[persist] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), persist
+        assert np.array_equal(to_np(tr).transpose(1, 0, 2), out[persist])
+    # same rounding points, other fp32 summation order
+    assert np.abs(out[True] - out[False]).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    m.dl_persist = True
+    m.use_graph = False                                  # eager launches of the same kernel
+    e = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.95, noise=torch.from_numpy(noise)))
+    assert np.array_equal(e, out[True])
+    m.use_graph = True
+    a = V.generate_t2v(m, torch.from_numpy(c), 3, torch.from_numpy(mk), seed=5)   # Philox draws: same stream in both samplers
+    m.dl_persist = False
+    b = V.generate_t2v(m, torch.from_numpy(c), 3, torch.from_numpy(mk), seed=5)
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
+
+
+def test_diffloss_persistent_sampler_bf16_full_width():
+    """BASELINE config-4 head: W 1024, depth 3, bf16, 32 rows (8 groups x 32 column tiles = 256 workgroups), 100 reverse steps.
+    Both samplers share rounding points; bf16 rounding amplifies summation-order differences over the chain, so the comparison
+    is on the first token and loose; two runs of the persistent sampler are bitwise identical."""
+    import video_llamagen_amd as V
+    m = V.Transformer(V.ModelArgs(dim=256, n_layer=2, n_head=4, block_size=64, cls_token_num=8, model_type="t2v", vae_embed_dim=8,
+                                  num_frames=17, t_downsample_size=4, caption_dim=64, head="hidden", diffloss_w=1024, diffloss_d=3,
+                                  num_sampling_steps=100)).to("cuda", torch.bfloat16)
+    m.init_random_weights(seed=4)
+    g = torch.Generator().manual_seed(1)
+    B, N = 32, 4
+    cond = torch.randn(B, 8, 64, generator=g) * 0.1
+    mask = torch.ones(B, 8)
+    noise = torch.randn(N, 101, B, 8, generator=g)
+    a = V.generate_t2v(m, cond, N, mask, noise=noise)
+    b = V.generate_t2v(m, cond, N, mask, noise=noise)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    m.dl_persist = False
+    c = V.generate_t2v(m, cond, N, mask, noise=noise)
+    scale = max(1.0, c[:, 0].abs().max().item())
+    assert (a[:, 0] - c[:, 0]).abs().max().item() < 8e-2 * scale
+    # fp32 handle of the same shape: tight agreement
+    m32 = V.Transformer(V.ModelArgs(dim=256, n_layer=2, n_head=4, block_size=64, cls_token_num=8, model_type="t2v", vae_embed_dim=8,
+                                    num_frames=17, t_downsample_size=4, caption_dim=64, head="hidden", diffloss_w=1024, diffloss_d=3,
+                                    num_sampling_steps=100)).to("cuda", torch.float32)
+    m32.init_random_weights(seed=4)
+    a32 = V.generate_t2v(m32, cond[:5], 2, mask[:5], noise=noise[:2, :, :5].contiguous())
+    m32.dl_persist = False
+    c32 = V.generate_t2v(m32, cond[:5], 2, mask[:5], noise=noise[:2, :, :5].contiguous())
+    assert torch.isfinite(a32).all() and (a32 - c32).abs().max().item() < 1e-3 * max(1.0, c32.abs().max().item())
+
+
 def test_full_width_decode_paths_agree():
     """BASELINE config-4 widths (GPT-XL: D 1280, 20 heads, F 3584, bf16, 32 rows, 120 text tokens) on a 2-layer stack: the exact
     kernel instances of the benchmark.  Size-independent properties: the fused-GEMM decode path, the slab path and the fused-QKV

@@ -23,12 +23,13 @@ struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
   DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
+  DevBuf dp_xbuf;                                           // persistent DiffLoss sampler: exchange buffer
   DevBuf rowsq;                                             // [D/16][64-padded rows] per-tile sums of squares of the residual stream (FusedGemm::sq_*)
   DevBuf maskbuf;                                           // this lane's rows of the caller's emb_mask (stable address for the cached graph)
   std::vector<uint64_t> ptr_key() const {                   // every address a captured decode step can hold
     std::vector<uint64_t> k;
     for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &attn_cnt, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
-                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf, &rowsq})
+                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf, &rowsq, &dp_xbuf})
       k.push_back((uint64_t)(uintptr_t)b->p);
     return k;
   }
@@ -59,6 +60,8 @@ struct vlg_gpt {
   std::vector<float> dsincos;        // [S][256] timestep embedding inputs
   DevBuf dtemb;                      // [S][W] time_embed(t) table, handle dtype
   DevBuf dadaln_bias;                // fp32 copy of diffloss.adaln_all.bias (bias operand of the batched modulation GEMM)
+  DevBuf dcoef_dev;                  // DdpmCoef[S] on the device (persistent sampler)
+  bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
   // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
@@ -397,6 +400,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->fuse_qkv = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "dl_persist")) {
+    h->dl_persist_on = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "gemm_lds")) {
     h->gemm_lds = value != 0;
     return VLG_OK;
@@ -728,6 +735,36 @@ struct Runner {
     }
     const T* wip = W<T>(p + "input_proj.weight");
     const T* bip = W<T>(p + "input_proj.bias");
+    // one lane only: two persistent launches on concurrent branches could each hold half of the CUs and wait for the other half
+    if (h->dl_persist_on && h->last_lanes == 1 && dl_persist_ok<T>(B, Wd, C, dd)) {
+      // all S reverse steps in one persistent launch (2 depth all-gathers per step between the workgroups of a 4-row group)
+      DlPersist dp{};
+      for (int blk = 0; blk < dd; ++blk) {
+        const std::string q = p + "res_blocks." + std::to_string(blk) + ".";
+        dp.ln_w[blk] = W<T>(q + "in_ln.weight");
+        dp.ln_b[blk] = W<T>(q + "in_ln.bias");
+        dp.w0[blk] = W<T>(q + "mlp.0.weight");
+        dp.b0[blk] = W<T>(q + "mlp.0.bias");
+        dp.w2[blk] = W<T>(q + "mlp.2.weight");
+        dp.b2[blk] = W<T>(q + "mlp.2.bias");
+      }
+      dp.wf = W<T>(p + "final_layer.linear.weight");
+      dp.bf = W<T>(p + "final_layer.linear.bias");
+      dp.wip = wip;
+      dp.bip = bip;
+      dp.mod_all = mod_all;
+      dp.coef = h->dcoef_dev.as<DdpmCoef>();
+      dp.noise = noise;
+      dp.state = state();
+      dp.xbuf = ln->dp_xbuf.p;
+      dp.cur = ln->cur_lat.as<float>();
+      dp.out_lat = out_lat + (size_t)b0 * N * C;
+      dp.trace = trace;
+      dp.depth = dd; dp.W = Wd; dp.C = C; dp.S = S; dp.B = B; dp.MR = MR; dp.N = N; dp.b_off = b0; dp.B_total = Btot;
+      dp.temperature = sp.temperature;
+      dp.seed = sp.seed;
+      return dl_persist<T>(dp, st);
+    }
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
     const bool ln_in_gemm = gemm_ln_fused_ok<T>(B, Wd, Wd) && gemm_ln_fused_ok<T>(B, 2 * C, Wd) && !getenv("VLG_DIFFLOSS_NO_LN_FUSE");
     DdpmCoef none{};
@@ -804,6 +841,8 @@ struct Runner {
     const int MR = (3 * h->dDepth + 2) * Wd;
     VLG_TRY(h->dadaln_bias.reserve((size_t)MR * sizeof(float)));
     VLG_TRY(upload_convert(h->dadaln_bias.p, VLG_F32, W<T>("diffloss.adaln_all.bias"), DT<T>::code, 1, MR, st));
+    VLG_TRY(h->dcoef_dev.reserve(h->dcoef.size() * sizeof(DdpmCoef)));
+    VLG_HIP(hipMemcpy(h->dcoef_dev.p, h->dcoef.data(), h->dcoef.size() * sizeof(DdpmCoef), hipMemcpyHostToDevice));
     h->dtemb_ready = true;
     return VLG_OK;
   }
@@ -913,6 +952,7 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
     VLG_TRY(ln.d_g1.reserve((size_t)Bp * Wd * e));
     VLG_TRY(ln.d_out.reserve((size_t)Bp * 2 * h->C * e));
     VLG_TRY(ln.d_x.reserve((size_t)Bp * h->C * e));
+    VLG_TRY(ln.dp_xbuf.reserve(dl_persist_xbuf_bytes(Bp, Wd, (int)e)));
   }
   VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
@@ -1055,7 +1095,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->fuse_qkv ? 4 : 0) | (h->attn_inlaunch ? 8 : 0) |
-                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0))};
+                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0) | (h->dl_persist_on ? 128 : 0)), (uint64_t)(uintptr_t)h->dcoef_dev.p};
       for (auto& r : rs) {
         key.push_back((uint64_t)(uintptr_t)r.st);
         const auto pk = r.ln->ptr_key();

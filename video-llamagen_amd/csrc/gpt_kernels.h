@@ -177,6 +177,37 @@ template <typename T>
 int dl_finish(const T* x, float* cur, float* out_lat, float* trace, const StepState* state, int B, int C, int N, int b_off, int B_total,
               hipStream_t st);
 
+// ---- persistent DiffLoss sampler (diffloss_persist.hip): all S reverse steps of one token in one launch ----------------------------
+struct DlPersist {
+  const void* ln_w[8];   // per ResBlock: in_ln weight / bias [W]
+  const void* ln_b[8];
+  const void* w0[8];     // mlp.0 [W, W], bias [W]
+  const void* b0[8];
+  const void* w2[8];     // mlp.2 [W, W], bias [W]
+  const void* b2[8];
+  const void* wf;        // final_layer.linear [2C, W], bias [2C]
+  const void* bf;
+  const void* wip;       // input_proj [W, C], bias [W]
+  const void* bip;
+  const void* mod_all;   // [S][B][MR] adaLN modulation vectors of every respaced step (MR = (3 depth + 2) W)
+  const DdpmCoef* coef;  // [S] device array
+  const float* noise;    // [N][S + 1][B_total][C] or null (Philox)
+  const StepState* state;
+  void* xbuf;            // exchange units {data, epoch}, dl_persist_xbuf_bytes (zeroed by the launcher)
+  float* cur;            // [B][C] next transformer input
+  float* out_lat;        // [B][N][C] (already offset to the lane's first sample)
+  float* trace;          // optional [N][B_total][C]
+  unsigned long long* prof;  // in-kernel time stamps (tools/microbench/dl_persist_lab.hip, -DVLG_DP_PROF builds only)
+  int depth, W, C, S, B, MR, N, b_off, B_total;
+  float temperature;
+  uint64_t seed;
+};
+size_t dl_persist_xbuf_bytes(int B, int W, int esz);
+template <typename T>
+bool dl_persist_ok(int B, int W, int C, int depth);
+template <typename T>
+int dl_persist(const DlPersist& p, hipStream_t st);
+
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
 template <typename T>

@@ -67,6 +67,7 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_gemm", C.c_int64(1 if model.fuse_gemm else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"attn_inlaunch", C.c_int64(1 if model.attn_inlaunch else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"gemm_lds", C.c_int64(1 if getattr(model, "gemm_lds", False) else 0)))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(1 if getattr(model, "dl_persist", True) else 0)))
         L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
                                          C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
                                          L.stream_ptr(dev)))

@@ -114,6 +114,7 @@ class Transformer:
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
         self.attn_inlaunch = False  # split-KV partials merged inside the attention launch (slower on MI355X, see gpt.hip)
         self.fuse_qkv = False    # decode: RoPE + KV append fused into the attention kernel
+        self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
         self.gemm_lds = False    # decode GEMMs on the LDS-DMA kernel with row statistics handed between kernels (see csrc/gemm_fused.hip)
         self.lanes = 0          # 0 = auto: independent batch lanes on forked graph branches (see csrc/gpt.hip)
 
