@@ -115,6 +115,19 @@ int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, co
  * session_step, whose first iteration runs the last condition token at position T-1 and samples token 0.  Waits for the prefill. */
 int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask);
 int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class);
+/* Block-granular KV cache (the role of vLLM's block manager behind serve/gpt_model.py:181-224).  With option "kv_block" = BS > 0
+ * (a power of two, 8..1024; set before session_begin) the session's cache is a pool of "kv_pool_blocks" blocks of BS positions
+ * (0 = enough for every slot at full length; block 0 is a scratch block for idle rows) instead of one slot of cls_token_num +
+ * max_new_tokens positions per row, so a slot holds memory for ITS request's length only.
+ *   session_reserve     gives `slot` (and its guidance partner) blocks for cls_token_num + n_tokens positions; call it before the
+ *                       request's prefill / start.  VLG_ERR_OOM (nothing changed) when the pool cannot cover it: keep the request
+ *                       queued and retry after a release.  Stepping a slot beyond its reservation is VLG_ERR_STATE.
+ *   session_release     returns the slot's blocks to the pool and idles the slot (after session_read).
+ *   session_free_blocks blocks currently free (-1 when the session has contiguous slots) and the block size.
+ * Without "kv_block" reserve / release succeed and change nothing.                                                              */
+int vlg_gpt_session_reserve(vlg_gpt_t* h, int32_t slot, int32_t n_tokens);
+int vlg_gpt_session_release(vlg_gpt_t* h, int32_t slot);
+int vlg_gpt_session_free_blocks(vlg_gpt_t* h, int32_t* n_free, int32_t* block_size);
 int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out);
 int vlg_gpt_session_end(vlg_gpt_t* h);
 
@@ -124,7 +137,8 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "fuse_qkv" (0: RoPE + KV append inside attention),
- * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "gemm_lds" (0: decode GEMMs
+ * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "dl_persist" (1: DiffLoss sampler
+ * as one persistent launch per token), "kv_block" / "kv_pool_blocks" (sessions, see above), "gemm_lds" (0: decode GEMMs
  * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto:
  * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);

@@ -201,6 +201,122 @@ def test_t2i_sessions_vs_reference_golden(golden):
         eng.add_request("x", None, sp, prompt_token_ids=[3])           # a text-conditioned engine takes features, not class ids
 
 
+def test_block_granular_kv_sessions_vs_reference_golden(golden):
+    """The iteration-level engine on a block-granular KV cache (vlg_gpt_session_reserve / release, paged attention + paged KV append):
+    ids equal the REFERENCE's generate().  Pools are sized so that (a) blocks are handed out in scrambled order and reused by later
+    requests, (b) an admission has to wait for a release (deferred > 0), (c) three requests of different lengths run side by side in
+    a pool that could not hold three full-length slots - shorter greedy requests are prefixes of the golden ids."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    g = golden("gpt")
+    cfg = cases.TINY_C2I
+    m, _ = product_gpt(cfg, torch.float32)
+    labels = [int(c) for c in cases.class_ids(3, cfg["num_classes"])]
+    N = cfg["block_size"]
+    null = cfg["num_classes"]
+
+    def run(engine, with_null, lens=(N, N, N)):
+        for i, c in enumerate(labels):
+            engine.add_request(str(i), None, V.SamplingParams(temperature=0.0, max_tokens=lens[i]), [c])
+        for i in range(3 if with_null else 0):
+            engine.add_request(str(3 + i), None, V.SamplingParams(temperature=0.0, max_tokens=lens[i]), [null])
+        outs = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+        return [np.array(outs[i]) for i in range(3)]
+
+    # 17 positions per request = 3 blocks of 8 per row.  7 blocks = scratch + two requests: the third waits for a release and
+    # then runs on blocks the first two returned
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=3, max_tokens=N, kv_block_size=8, num_kv_blocks=7)
+    out = run(e, False)
+    assert all((out[i] == g["c2i_fp32_greedy_ids"][i]).all() for i in range(3)) and e.deferred > 0
+    e = V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=6, max_tokens=N, kv_block_size=8, num_kv_blocks=13)
+    out = run(e, True)
+    assert all((out[i] == g["c2i_fp32_cfg_ids"][i]).all() for i in range(3)) and e.deferred > 0
+    # default pool (every slot at full length), block 16
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=2, max_tokens=N, kv_block_size=16)
+    out = run(e, False)
+    assert all((out[i] == g["c2i_fp32_greedy_ids"][i]).all() for i in range(3))
+    # lengths 16 / 7 / 3 tokens need 3 + 1 + 1 blocks: they run together in 6 blocks, where three full-length slots would need 10
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=3, max_tokens=N, kv_block_size=8, num_kv_blocks=6)
+    lens = (N, 7, 3)
+    out = run(e, False, lens)
+    assert e.deferred == 0
+    for i in range(3):
+        assert len(out[i]) == lens[i] and (out[i] == g["c2i_fp32_greedy_ids"][i][:lens[i]]).all(), i
+
+    # text-conditioned: 120 condition positions + 16 tokens = 9 blocks of 16 per row (18 per request under guidance)
+    cfg = cases.TINY_T2I
+    m, _ = product_gpt(cfg, torch.float32)
+    c, mk = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[120, 3, 57])
+    N = cfg["block_size"]
+    sp = V.SamplingParams(temperature=0.0, max_tokens=N)
+
+    def run_t(engine):
+        for i in range(3):
+            engine.add_request(str(i), None, sp, prompt_embeds=torch.from_numpy(c[i]), emb_mask=torch.from_numpy(mk[i]))
+        outs = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+        return np.array([outs[i] for i in range(3)])
+
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=3, kv_block_size=16, num_kv_blocks=1 + 2 * 9)
+    assert (run_t(e) == g["t2i_fp32_greedy_ids"]).all() and e.deferred > 0
+    e = V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=3, kv_block_size=16, num_kv_blocks=1 + 2 * 18)
+    assert (run_t(e) == g["t2i_fp32_cfg_ids"]).all() and e.deferred > 0
+    e = V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=2, kv_block_size=32)
+    assert (run_t(e) == g["t2i_fp32_cfg_ids"]).all()
+
+
+def test_block_granular_kv_error_paths():
+    import ctypes as C
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib as L
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    m, _ = product_gpt(cases.TINY_C2I, torch.float32)
+    m._ensure_handle()
+    lib, h = L.lib(), m._handle
+    sp = L.SamplingParams(cfg_scale=1.0, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=0, seed=0)
+    with pytest.raises(L.VlgError):
+        L.check(lib.vlg_gpt_set_option(h, b"kv_block", C.c_int64(24)))          # not a power of two
+    L.check(lib.vlg_gpt_set_option(h, b"kv_block", C.c_int64(8)))
+    L.check(lib.vlg_gpt_set_option(h, b"kv_pool_blocks", C.c_int64(4)))         # scratch + 3
+    L.check(lib.vlg_gpt_session_begin(h, 2, 16, C.byref(sp)))
+    nfree, bs = C.c_int32(0), C.c_int32(0)
+    L.check(lib.vlg_gpt_session_free_blocks(h, C.byref(nfree), C.byref(bs)))
+    assert (nfree.value, bs.value) == (3, 8)
+    rc = (C.c_int32 * 2)(5, -2)
+    assert lib.vlg_gpt_session_step(h, rc) == L.VLG_ERR_STATE                   # start without a reservation
+    L.check(lib.vlg_gpt_session_reserve(h, 0, 7))                               # 8 positions: one block
+    assert lib.vlg_gpt_session_reserve(h, 1, 16) == L.VLG_ERR_OOM               # 3 blocks wanted, 2 free: nothing changes
+    L.check(lib.vlg_gpt_session_free_blocks(h, C.byref(nfree), None))
+    assert nfree.value == 2
+    L.check(lib.vlg_gpt_session_step(h, rc))
+    rc[0] = -1
+    for _ in range(6):
+        L.check(lib.vlg_gpt_session_step(h, rc))                                # positions 1..6 (tokens 1..6 sampled, 7 in all)
+    L.check(lib.vlg_gpt_session_step(h, rc))                                    # position 7: the last one of the block
+    assert lib.vlg_gpt_session_step(h, rc) == L.VLG_ERR_STATE                   # position 8 is outside the reservation
+    L.check(lib.vlg_gpt_session_reserve(h, 0, 16))                              # grow: 2 more blocks
+    L.check(lib.vlg_gpt_session_free_blocks(h, C.byref(nfree), None))
+    assert nfree.value == 0
+    L.check(lib.vlg_gpt_session_release(h, 0))
+    L.check(lib.vlg_gpt_session_free_blocks(h, C.byref(nfree), None))
+    assert nfree.value == 3
+    L.check(lib.vlg_gpt_session_end(h))
+    L.check(lib.vlg_gpt_set_option(h, b"kv_block", C.c_int64(0)))
+    L.check(lib.vlg_gpt_set_option(h, b"kv_pool_blocks", C.c_int64(0)))
+    L.check(lib.vlg_gpt_session_begin(h, 2, 16, C.byref(sp)))                   # contiguous slots: reserve / release are no-ops
+    L.check(lib.vlg_gpt_session_reserve(h, 0, 16))
+    L.check(lib.vlg_gpt_session_free_blocks(h, C.byref(nfree), C.byref(bs)))
+    assert (nfree.value, bs.value) == (-1, 0)
+    L.check(lib.vlg_gpt_session_end(h))
+
+
 def test_session_and_t5_error_paths():
     """Loud failures instead of silent fallbacks: sessions on a text-conditioned model, stepping without a session, slot overrun,
     T5 configurations / sequence lengths that are not built."""

@@ -10,6 +10,7 @@ VLG_F32, VLG_BF16 = 0, 1
 VLG_C2I, VLG_T2I, VLG_T2V = 0, 1, 2
 VLG_HEAD_LOGITS, VLG_HEAD_ADAPTER2, VLG_HEAD_HIDDEN = 0, 1, 2
 
+VLG_OK, VLG_ERR_BAD_ARG, VLG_ERR_BAD_SHAPE, VLG_ERR_UNSUPPORTED, VLG_ERR_OOM, VLG_ERR_HIP, VLG_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 STATUS = {0: "VLG_OK", -1: "VLG_ERR_BAD_ARG", -2: "VLG_ERR_BAD_SHAPE", -3: "VLG_ERR_UNSUPPORTED",
           -4: "VLG_ERR_OOM", -5: "VLG_ERR_HIP", -6: "VLG_ERR_STATE"}
 
@@ -60,6 +61,7 @@ SYMBOLS = [
     "vlg_gpt_create", "vlg_gpt_destroy", "vlg_gpt_load_tensor", "vlg_gpt_generate",
     "vlg_gpt_last_algorithmic_bytes", "vlg_gpt_graphs_built", "vlg_gpt_set_option", "vlg_gpt_attn_timing", "vlg_gpt_attn_event_overhead",
     "vlg_gpt_session_begin", "vlg_gpt_session_prefill", "vlg_gpt_session_step", "vlg_gpt_session_read", "vlg_gpt_session_end",
+    "vlg_gpt_session_reserve", "vlg_gpt_session_release", "vlg_gpt_session_free_blocks",
     "vlg_rmsnorm", "vlg_linear", "vlg_rope_table", "vlg_sample", "vlg_attn_decode",
     "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",
     "vlg_codebook_argmin", "vlg_codebook_forward", "vlg_causal_conv3d", "vlg_group_norm", "vlg_time_upsample2x",

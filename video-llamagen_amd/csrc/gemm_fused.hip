@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       if (sec == 0)
         dst = reinterpret_cast<T*>(fa.qbuf) + ((size_t)row * fa.H + hh) * fa.hd + d;
       else
-        dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + (((size_t)bq * fa.H + hh) * fa.S + p) * fa.hd + d;
+        dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + kv_row_index(fa.pages, bq, hh, fa.H, fa.S, p) * fa.hd + d;
       DT<T>::st(dst, o);
     }
   }
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_lds_kernel(const T* __restrict__
         if (sec == 0)
           dst = reinterpret_cast<T*>(fa.qbuf) + ((size_t)row * fa.H + hh) * fa.hd + d;
         else
-          dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + (((size_t)bq * fa.H + hh) * fa.S + p) * fa.hd + d;
+          dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + kv_row_index(fa.pages, bq, hh, fa.H, fa.S, p) * fa.hd + d;
         DT<T>::st(dst, o);
       }
     }

@@ -61,6 +61,8 @@ struct vlg_gpt {
   DevBuf dtemb;                      // [S][W] time_embed(t) table, handle dtype
   DevBuf dadaln_bias;                // fp32 copy of diffloss.adaln_all.bias (bias operand of the batched modulation GEMM)
   DevBuf dcoef_dev;                  // DdpmCoef[S] on the device (persistent sampler)
+  int kv_block = 0;                  // sessions: positions per KV block (0 = one contiguous slot of max length per row)
+  int kv_pool_blocks = 0;            //           blocks in the pool, scratch block included (0 = enough for every row at full length)
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
@@ -400,6 +402,16 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->fuse_qkv = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "kv_block")) {
+    VLG_CHECK(value == 0 || (value >= 8 && value <= 1024 && (value & (value - 1)) == 0), VLG_ERR_BAD_ARG, "kv_block must be 0 or a power of two in 8..1024");
+    h->kv_block = (int)value;
+    return VLG_OK;
+  }
+  if (!strcmp(key, "kv_pool_blocks")) {
+    VLG_CHECK(value >= 0 && value < (1 << 24), VLG_ERR_BAD_ARG, "kv_pool_blocks out of range");
+    h->kv_pool_blocks = (int)value;
+    return VLG_OK;
+  }
   if (!strcmp(key, "dl_persist")) {
     h->dl_persist_on = value != 0;
     return VLG_OK;
@@ -465,8 +477,13 @@ struct Runner {
   const int32_t* row_step = nullptr;
   int kv_row0 = 0, kv_rows = 0;        // this runner's rows are rows kv_row0.. of a cache holding kv_rows batch rows (0 = Bp): slot prefill
   const void* pending = nullptr;       // sessions of text-conditioned models: [rows][D] input rows of slots that start this step
-  size_t kv_lstride() const { return (size_t)(kv_rows ? kv_rows : Bp) * h->H * S * h->hd; }
-  size_t kv_off() const { return (size_t)kv_row0 * h->H * S * h->hd; }
+  KvPages pages{};                     // sessions with a block-granular cache: block table of THIS runner's rows
+  int pool_blocks = 0;                 //   and the number of blocks in the per-layer pool
+  size_t kv_lstride() const {
+    if (pages.table) return ((size_t)pool_blocks * h->H << pages.shift) * h->hd;
+    return (size_t)(kv_rows ? kv_rows : Bp) * h->H * S * h->hd;
+  }
+  size_t kv_off() const { return pages.table ? 0 : (size_t)kv_row0 * h->H * S * h->hd; }
   StepState* state() { return ln->state.as<StepState>(); }
   int* attn_cnt() { return h->attn_inlaunch ? ln->attn_cnt.as<int>() : nullptr; }
   template <typename U>
@@ -494,15 +511,15 @@ struct Runner {
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
       T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
-      const bool fused = (Tq == 1) && h->fuse_qkv;
-      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos));
+      const bool fused = (Tq == 1) && h->fuse_qkv && pages.table == nullptr;
+      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos, pages));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt(), row_pos));
+                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt(), row_pos, pages));
       VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
@@ -558,6 +575,7 @@ struct Runner {
       fa.freqs = h->freqs.as<float>();
       fa.state = state();
       fa.row_pos = row_pos;
+      fa.pages = pages;
       fa.Tq = 1;
       fa.H = H;
       fa.hd = hd;
@@ -575,7 +593,7 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
-                           st, e0, e1, nullptr, 0, nullptr, attn_cnt(), row_pos));
+                           st, e0, e1, nullptr, 0, nullptr, attn_cnt(), row_pos, pages));
       FusedGemm fr;
       fr.h = x;
       fr.lds = h->gemm_lds;
@@ -917,12 +935,13 @@ struct Runner {
   }
 };
 
-int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S) {
+int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0, int kv_block = 0) {
   const int Tc = h->Tc, D = h->D, H = h->H, hd = h->hd, F = h->F;
   const int M = Bp * Tc;  // prefill rows
   const size_t e = h->esz;
-  VLG_TRY(ln.kcache.reserve((size_t)h->L * Bp * H * S * hd * e));
-  VLG_TRY(ln.vcache.reserve((size_t)h->L * Bp * H * S * hd * e));
+  const size_t kv_elems = pool_blocks > 0 ? (size_t)h->L * pool_blocks * H * kv_block * hd : (size_t)h->L * Bp * H * S * hd;
+  VLG_TRY(ln.kcache.reserve(kv_elems * e));
+  VLG_TRY(ln.vcache.reserve(kv_elems * e));
   size_t wsf = 0;
   auto need = [&](int m, int n, int k) { wsf = std::max(wsf, gemm_ws_floats(m, n, k, (int)e)); };
   for (int m : {M, Bp}) {
@@ -1183,6 +1202,22 @@ struct vlg_gpt::Session {
   std::vector<char> prefilled;        // slot has a condition in its KV rows and waits for its first step
   std::vector<int32_t> pos;           // host mirror: -1 = idle, else input position of the slot's next step
   std::vector<int32_t> h_pos, h_step, h_cls;
+  // block-granular cache (option kv_block): table [Rp][nblk_row] of pool block ids, 0 = the scratch block idle rows run on
+  int bs_shift = 0, nblk_row = 0, pool_blocks = 0;
+  DevBuf btab;
+  std::vector<int32_t> h_btab, free_blocks;
+  std::vector<int32_t> reserved;      // per slot: positions covered by its blocks
+  bool btab_dirty = false;
+  bool paged() const { return pool_blocks > 0; }
+  KvPages pages(int row0 = 0) const {
+    KvPages pg;
+    if (paged()) {
+      pg.table = btab.as<int32_t>() + (size_t)row0 * nblk_row;
+      pg.stride = nblk_row;
+      pg.shift = bs_shift;
+    }
+    return pg;
+  }
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   ~Session() {
@@ -1201,7 +1236,24 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   ses->maxN = maxN;
   ses->S = round_up(h->Tc + maxN, 8);
   ses->sp = sp;
-  VLG_TRY(reserve_lane(h, ses->ln, R, ses->Rp, ses->S));
+  if (h->kv_block > 0) {
+    int sh = 0;
+    while ((1 << sh) < h->kv_block) ++sh;
+    ses->bs_shift = sh;
+    ses->nblk_row = cdiv(ses->S, h->kv_block);
+    VLG_CHECK(ses->nblk_row <= 256, VLG_ERR_BAD_SHAPE, "kv_block %d: %d blocks per row, at most 256", h->kv_block, ses->nblk_row);
+    ses->pool_blocks = h->kv_pool_blocks > 0 ? h->kv_pool_blocks : ses->Rp * ses->nblk_row + 1;
+    VLG_CHECK(ses->pool_blocks >= 2, VLG_ERR_BAD_ARG, "kv_pool_blocks %d: the pool needs the scratch block and at least one more", ses->pool_blocks);
+    // the lane's cache buffers hold L pools of pool_blocks * H * BS * hd elements: expressed as (rows = pool_blocks, S = BS)
+    VLG_TRY(reserve_lane(h, ses->ln, R, ses->Rp, ses->S, ses->pool_blocks, h->kv_block));
+    ses->h_btab.assign((size_t)ses->Rp * ses->nblk_row, 0);
+    VLG_TRY(ses->btab.reserve(ses->h_btab.size() * sizeof(int32_t)));
+    VLG_HIP(hipMemset(ses->btab.p, 0, ses->h_btab.size() * sizeof(int32_t)));
+    for (int i = ses->pool_blocks - 1; i >= 1; --i) ses->free_blocks.push_back(i);   // block 0 = scratch
+    ses->reserved.assign(R, 0);
+  } else {
+    VLG_TRY(reserve_lane(h, ses->ln, R, ses->Rp, ses->S));
+  }
   const size_t nb = (size_t)ses->Rp * sizeof(int32_t);
   VLG_TRY(ses->row_pos.reserve(nb));
   VLG_TRY(ses->row_step.reserve(nb));
@@ -1230,6 +1282,8 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   r.row_pos = ses->row_pos.as<int32_t>();
   r.row_step = ses->row_step.as<int32_t>();
   r.pending = ses->pending.p;
+  r.pages = ses->pages();
+  r.pool_blocks = ses->pool_blocks;
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1252,6 +1306,11 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   for (int b = 0; b < R; ++b) {
     const int c = h_row_class[b];
     int cls = -1, cls_partner = -1;
+    if (s.paged() && (c >= 0 || c == -3 || (c == -1 && s.pos[b] >= 0))) {
+      const int next = (c == -1) ? s.pos[b] + 1 : (text ? first : 0);
+      VLG_CHECK(next < s.reserved[b], VLG_ERR_STATE, "slot %d: position %d is outside its reserved KV blocks (%d positions; vlg_gpt_session_reserve)",
+                b, next, s.reserved[b]);
+    }
     if (c >= 0 && !text) {             // start a class-conditional request in this slot
       VLG_CHECK(c <= null_cls, VLG_ERR_BAD_ARG, "class id %d out of range", c);
       s.pos[b] = 0;
@@ -1287,6 +1346,10 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   VLG_HIP(hipMemcpyAsync(s.row_pos.p, s.h_pos.data(), nb, hipMemcpyHostToDevice, st));
   VLG_HIP(hipMemcpyAsync(s.row_step.p, s.h_step.data(), nb, hipMemcpyHostToDevice, st));
   VLG_HIP(hipMemcpyAsync(s.row_cls.p, s.h_cls.data(), nb, hipMemcpyHostToDevice, st));
+  if (s.btab_dirty) {
+    VLG_HIP(hipMemcpyAsync(s.btab.p, s.h_btab.data(), s.h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    s.btab_dirty = false;
+  }
   if (s.exec) {
     VLG_HIP(hipGraphLaunch(s.exec, st));
   } else {
@@ -1294,6 +1357,8 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
     r.row_pos = s.row_pos.as<int32_t>();
     r.row_step = s.row_step.as<int32_t>();
     r.pending = s.pending.p;
+    r.pages = s.pages();
+    r.pool_blocks = s.pool_blocks;
     VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>()));
   }
   // the host arrays are reused by the next call: the copies above must have been consumed
@@ -1319,10 +1384,20 @@ int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float*
     VLG_HIP(hipMemcpyAsync(mrow, ones.data(), (size_t)Tc * sizeof(float), hipMemcpyHostToDevice, st));
     VLG_HIP(hipStreamSynchronize(st));
   }
+  if (s.paged()) {
+    VLG_CHECK(s.reserved[slot] >= Tc, VLG_ERR_STATE, "slot %d: reserve its KV blocks first (vlg_gpt_session_reserve)", slot);
+    if (s.btab_dirty) {
+      VLG_HIP(hipMemcpyAsync(s.btab.p, s.h_btab.data(), s.h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      VLG_HIP(hipStreamSynchronize(st));
+      s.btab_dirty = false;
+    }
+  }
   for (int pass = 0; pass < (s.cfg ? 2 : 1); ++pass) {
     Runner<T> r{h, &s.ln, st, 1, 1, s.maxN, s.S, 0, 1, mrow};
     r.kv_row0 = slot + pass * s.R;
     r.kv_rows = s.Rp;
+    r.pages = s.pages(r.kv_row0);
+    r.pool_blocks = s.pool_blocks;
     VLG_TRY(set_state(r.state(), 0, 0, st));
     // pass 0: the request's caption features; pass 1: uncond_embedding (generate.py:138-139)
     VLG_TRY(build_text_cond<T>(d_cond, r.template W<T>("cls_embedding.uncond_embedding"), s.ln.condT.as<T>(), pass == 0 ? 1 : 0, 1, Tc, cd, st));
@@ -1344,6 +1419,57 @@ extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* 
   VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
   h->ses->pos[slot] = -1;   // whatever ran in the slot is over: the caller reuses it (its tokens were read with session_read)
   return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
+}
+
+extern "C" int vlg_gpt_session_reserve(vlg_gpt_t* h, int32_t slot, int32_t n_tokens) {
+  VLG_CHECK(h && h->ses != nullptr, VLG_ERR_STATE, "vlg_gpt_session_reserve: no open session");
+  vlg_gpt::Session& s = *h->ses;
+  VLG_CHECK(slot >= 0 && slot < s.R && n_tokens > 0 && n_tokens <= s.maxN, VLG_ERR_BAD_ARG, "vlg_gpt_session_reserve: slot %d / %d tokens out of range", slot,
+            n_tokens);
+  if (!s.paged()) return VLG_OK;   // contiguous slots are sized for max_new_tokens already
+  const int bs = 1 << s.bs_shift, rows = s.cfg ? 2 : 1;
+  const int want = cdiv(h->Tc + n_tokens, bs), have = cdiv(s.reserved[slot], bs);
+  if (want > have) {
+    const int need = (want - have) * rows;
+    if ((int)s.free_blocks.size() < need) {
+      set_error("KV pool: slot %d needs %d more blocks, %d are free", slot, need, (int)s.free_blocks.size());
+      return VLG_ERR_OOM;
+    }
+    for (int r = 0; r < rows; ++r)
+      for (int j = have; j < want; ++j) {
+        s.h_btab[(size_t)(slot + r * s.R) * s.nblk_row + j] = s.free_blocks.back();
+        s.free_blocks.pop_back();
+      }
+    s.btab_dirty = true;
+  }
+  s.reserved[slot] = std::max(s.reserved[slot], std::min(want * bs, s.S));
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_session_release(vlg_gpt_t* h, int32_t slot) {
+  VLG_CHECK(h && h->ses != nullptr, VLG_ERR_STATE, "vlg_gpt_session_release: no open session");
+  vlg_gpt::Session& s = *h->ses;
+  VLG_CHECK(slot >= 0 && slot < s.R, VLG_ERR_BAD_ARG, "vlg_gpt_session_release: slot %d out of range", slot);
+  s.pos[slot] = -1;
+  s.prefilled[slot] = 0;
+  if (!s.paged()) return VLG_OK;
+  // the step that last used these blocks has been waited for (session_step synchronises its stream before it returns)
+  for (int r = 0; r < (s.cfg ? 2 : 1); ++r)
+    for (int j = 0; j < s.nblk_row; ++j) {
+      int32_t& e = s.h_btab[(size_t)(slot + r * s.R) * s.nblk_row + j];
+      if (e != 0) s.free_blocks.push_back(e);
+      e = 0;
+    }
+  s.reserved[slot] = 0;
+  s.btab_dirty = true;
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_session_free_blocks(vlg_gpt_t* h, int32_t* n_free, int32_t* block_size) {
+  VLG_CHECK(h && h->ses != nullptr && n_free, VLG_ERR_STATE, "vlg_gpt_session_free_blocks: no open session / null argument");
+  *n_free = h->ses->paged() ? (int32_t)h->ses->free_blocks.size() : -1;
+  if (block_size) *block_size = h->ses->paged() ? (1 << h->ses->bs_shift) : 0;
+  return VLG_OK;
 }
 
 extern "C" int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp) {

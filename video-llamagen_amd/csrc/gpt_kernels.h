@@ -13,6 +13,21 @@ struct StepState {
 // ARGUMENTS (null = uniform mode): a pointer kept inside StepState would put a dependent load in front of every kernel's first
 // address computation (measured: +1 us on the QKV GEMM).
 
+// Block-granular KV cache (vlg_gpt_session_* with option kv_block): per layer the cache is a POOL [n_blocks][H][BS][hd] instead of
+// [rows][H][S][hd]; batch row b keeps positions j*BS .. j*BS+BS-1 in pool block table[b * stride + j].  table == nullptr: contiguous.
+// (serve/gpt_model.py:181-224 runs on vLLM's paged KV; block 0 is a scratch block every idle row's table points at.)
+struct KvPages {
+  const int32_t* table = nullptr;
+  int stride = 0;   // table entries per batch row (<= 256)
+  int shift = 0;    // log2(BS)
+};
+// index of cache row (b, h, p) in units of hd elements
+__host__ __device__ inline size_t kv_row_index(const KvPages& pg, int b, int h, int H, int S, int p) {
+  if (pg.table == nullptr) return ((size_t)b * H + h) * S + p;
+  const size_t blk = (size_t)pg.table[(size_t)b * pg.stride + (p >> pg.shift)];
+  return (((blk * H + h) << pg.shift) | (size_t)(p & ((1 << pg.shift) - 1)));
+}
+
 enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_SILU = 2 };
 
 // ---- GEMM: slabs[s][M][N] (fp32 partial sums over a K slice) = x[M,K] @ w[N,K]^T -----------------
@@ -40,6 +55,7 @@ struct FusedGemm {
   const StepState* state = nullptr;
   const int32_t* row_pos = nullptr;   // EPI_QKV, sessions: position of batch row b instead of state->pos
   int Tq = 1, H = 0, hd = 0, S = 0;
+  KvPages pages;                  // EPI_QKV: block-granular cache (sessions)
   void* out = nullptr;            // EPI_SWIGLU: g [M,N]; EPI_STORE: out [M,N] (T)
   float* out_f32 = nullptr;       // EPI_STORE
   const void* bias = nullptr;     // EPI_STORE (dtype T)
@@ -106,7 +122,8 @@ int reduce_silu_mul(const float* ws, int splits, T* g, int M, int F, hipStream_t
 // caches: [Bp, H, S, hd]; rows m = b*Tq + t.  freqs: fp32 [npos, hd/2, 2]          (gpt.py:215-227)
 template <typename T>
 int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache, const float* freqs,
-                     const StepState* state, int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos = nullptr);
+                     const StepState* state, int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos = nullptr,
+                     KvPages pages = KvPages{});
 
 // attention of every query row m = b*Tq + t (position p = state->pos + t) over keys 0..p of batch b
 // (gpt.py:230-237 with the mask of generate.py:156-165).  out [M, H*hd].
@@ -121,7 +138,8 @@ int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, co
               // counters != null: the splits are merged inside the launch by the last-arriving workgroup of each (row, head)
               // (no attn_combine launch).  M*H ints, zero before the first launch; every launch leaves them zero.
               int* counters = nullptr,
-              const int32_t* row_pos = nullptr);   // sessions: batch row b attends keys 0..row_pos[b] (+t)
+              const int32_t* row_pos = nullptr,    // sessions: batch row b attends keys 0..row_pos[b] (+t)
+              KvPages pages = KvPages{});          // sessions with a block-granular cache
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
                                                                T* __restrict__ kc, T* __restrict__ vc,
                                                                const float* __restrict__ freqs,
                                                                const StepState* __restrict__ state, int M, int Tq, int H,
-                                                               int hd, int S, const int32_t* __restrict__ row_pos) {
+                                                               int hd, int S, const int32_t* __restrict__ row_pos, KvPages pages) {
   const int D = H * hd;
   const int pairs = 3 * D / 2;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -613,23 +613,23 @@ __global__ __launch_bounds__(256) void qkv_rope_scatter_kernel(const float* __re
   if (sec == 0)
     dst = qbuf + ((size_t)m * H + hh) * hd + d;
   else
-    dst = (sec == 1 ? kc : vc) + (((size_t)b * H + hh) * S + p) * hd + d;
+    dst = (sec == 1 ? kc : vc) + kv_row_index(pages, b, hh, H, S, p) * hd + d;
   DT<T>::st(dst, o0);
   DT<T>::st(dst + 1, o1);
 }
 
 template <typename T>
 int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache, const float* freqs, const StepState* state,
-                     int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos) {
+                     int M, int Tq, int H, int hd, int S, hipStream_t st, const int32_t* row_pos, KvPages pages) {
   long long n = (long long)M * (3 * H * hd / 2);
   qkv_rope_scatter_kernel<T><<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(ws, splits, qbuf, kcache, vcache, freqs, state,
-                                                                                M, Tq, H, hd, S, row_pos);
+                                                                                M, Tq, H, hd, S, row_pos, pages);
   return VLG_OK;
 }
 template int qkv_rope_scatter<float>(const float*, int, float*, float*, float*, const float*, const StepState*, int, int, int, int, int, hipStream_t,
-                                     const int32_t*);
+                                     const int32_t*, KvPages);
 template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, const float*, const StepState*, int, int, int, int, int, hipStream_t,
-                                    const int32_t*);
+                                    const int32_t*, KvPages);
 
 // ------------------------------------------------------------------------------------------------
 // split-KV attention for one query row per (row m, head h)
@@ -648,13 +648,15 @@ struct FusedQKV {
   const float* freqs;   // [npos][HD/2][2]
 };
 
-template <typename T, int HD, int VEC, int LPR, bool FUSED, int U>
+// PAGED: block-granular cache (KvPages); the batch row's block table is staged in LDS and every cache row address goes through it.
+template <typename T, int HD, int VEC, int LPR, bool FUSED, int U, bool PAGED = false>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__ qbuf, T* __restrict__ kc,
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
                                                            int Tc, float scale, FusedQKV fq, int* __restrict__ counters,
-                                                           const int32_t* __restrict__ row_pos) {
+                                                           const int32_t* __restrict__ row_pos, KvPages pg = KvPages{}) {
+  static_assert(!(PAGED && FUSED), "the fused-QKV form appends to a contiguous cache");
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
@@ -712,8 +714,20 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < VEC; ++j) qf[j] = active ? DT<T>::ld(&qp.v[j]) : 0.f;
   }
-  T* kbase = kc + ((size_t)b * H + h) * (size_t)S * HD + coff;
-  T* vbase = vc + ((size_t)b * H + h) * (size_t)S * HD + coff;
+  __shared__ int32_t blk_s[PAGED ? 256 : 1];
+  if constexpr (PAGED) {
+    for (int i = threadIdx.x; i < pg.stride; i += 256) blk_s[i] = pg.table[(size_t)b * pg.stride + i];
+    __syncthreads();
+  }
+  T* kbase = PAGED ? kc + (((size_t)h << pg.shift) * HD + coff) : kc + ((size_t)b * H + h) * (size_t)S * HD + coff;
+  T* vbase = PAGED ? vc + (((size_t)h << pg.shift) * HD + coff) : vc + ((size_t)b * H + h) * (size_t)S * HD + coff;
+  // offset (elements) of cache row rr from kbase / vbase
+  auto rowoff = [&](int rr) -> size_t {
+    if constexpr (PAGED)
+      return ((((size_t)blk_s[rr >> pg.shift] * H) << pg.shift) + (size_t)(rr & ((1 << pg.shift) - 1))) * HD;
+    else
+      return (size_t)rr * HD;
+  };
   const float* mrow = (mask != nullptr) ? mask + (size_t)(b % Bmask) * Tc : nullptr;
 
   float mx = -INFINITY, l = 0.f, acc[VEC];
@@ -727,8 +741,9 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
     for (int u = 0; u < U; ++u) {
       rows[u] = tile + u * RPI + g;
       const int rr = rows[u] < r1 ? rows[u] : r1 - 1;
-      kk[u] = load_stream<T, VEC>(kbase + (size_t)rr * HD);
-      vv[u] = load_stream<T, VEC>(vbase + (size_t)rr * HD);
+      const size_t ro = rowoff(rr);
+      kk[u] = load_stream<T, VEC>(kbase + ro);
+      vv[u] = load_stream<T, VEC>(vbase + ro);
       if constexpr (FUSED) {
         // row p (the row this step appends) is not in the cache yet: every lane that addresses it - its owner and the
         // out-of-range lanes clamped onto it - takes the in-register copy (stale cache bits could be NaN: 0 * NaN);
@@ -913,7 +928,7 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                       const FusedQKV* fq, int* counters, const int32_t* row_pos) {
+                       const FusedQKV* fq, int* counters, const int32_t* row_pos, KvPages pages) {
   const int M = Bp * Tq;
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
   // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
@@ -927,7 +942,14 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
   if (nsplit < 1) nsplit = 1;
   const float scale = 1.0f / sqrtf((float)HD);
   if (ev0) (void)hipEventRecord(ev0, st);
-  if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
+  if (pages.table != nullptr) {
+    if (fq != nullptr || pages.stride > 256) {
+      set_error("block-granular KV: fused-QKV attention is not available, and a row may hold at most 256 blocks (has %d)", pages.stride);
+      return VLG_ERR_UNSUPPORTED;
+    }
+    attn_partial_kernel<T, HD, VEC, LPR, false, 4, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale,
+                                                                                            FusedQKV{nullptr, 0, nullptr}, counters, row_pos, pages);
+  } else if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
     if constexpr (VEC % 2 == 0)
       attn_partial_kernel<T, HD, VEC, LPR, true, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
                                                                                       Tc, scale, *fq, counters, row_pos);
@@ -955,11 +977,11 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
 template <typename T>
 int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
               int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters, const int32_t* row_pos) {
+              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters, const int32_t* row_pos, KvPages pages) {
   FusedQKV fqv{qkv_ws, qkv_splits, freqs};
   const FusedQKV* fq = qkv_ws ? &fqv : nullptr;
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters, row_pos)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters, row_pos, pages)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -977,8 +999,8 @@ int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* s
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*);
-template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*, KvPages);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*, KvPages);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels

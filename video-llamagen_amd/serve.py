@@ -179,7 +179,11 @@ class ContinuousLLMEngine:
     """Iteration-level scheduler (vLLM's scheduler + model runner loop, llm_engine.py `step`): slots instead of waves.  All requests of
     a session share the sampling parameters of the first one except `max_tokens` (<= the session's)."""
 
-    def __init__(self, model, cfg_scale=1.0, cfg_interval=-1, max_num_seqs=256, seed=0, max_tokens=None):
+    def __init__(self, model, cfg_scale=1.0, cfg_interval=-1, max_num_seqs=256, seed=0, max_tokens=None, kv_block_size=0,
+                 num_kv_blocks=0):
+        """kv_block_size > 0: block-granular KV cache (vLLM's `block_size` / `num_gpu_blocks`): every request reserves blocks for ITS
+        length at admission and returns them when it finishes; a request the pool cannot cover yet stays queued.  num_kv_blocks = 0
+        sizes the pool for every slot at full length."""
         import ctypes as C
         from . import _lib as L
         self._C, self._L = C, L
@@ -190,6 +194,8 @@ class ContinuousLLMEngine:
         self.text = model.model_type == "t2i"         # conditions are caption features: prefilled per slot, guidance partner internal
         self.slots_n = max(1, max_num_seqs // 2 if (self.cfg and not self.text) else max_num_seqs)
         self.max_tokens = max_tokens
+        self.kv_block_size, self.num_kv_blocks = int(kv_block_size), int(num_kv_blocks)
+        self.deferred = 0                             # admissions postponed because the KV pool was full
         self.waiting = collections.deque()
         self.pending_null = collections.deque()      # null-class partner requests (reported with their partner's tokens)
         self.slots = [None] * self.slots_n           # (request, tokens done, partner request or None)
@@ -230,8 +236,25 @@ class ContinuousLLMEngine:
                              top_k=0 if sp.top_k == -1 else int(sp.top_k), top_p=float(sp.top_p), sample_logits=1 if sp.temperature > 0 else 0,
                              seed=int(sp.seed if sp.seed is not None else self.seed))
         with torch.cuda.device(self.model._device):
+            L.check(L.lib().vlg_gpt_set_option(self.model._handle, b"kv_block", C.c_int64(self.kv_block_size)))
+            L.check(L.lib().vlg_gpt_set_option(self.model._handle, b"kv_pool_blocks", C.c_int64(self.num_kv_blocks)))
             L.check(L.lib().vlg_gpt_session_begin(self.model._handle, self.slots_n, n, C.byref(c)))
         self._open, self._params, self.session_tokens = True, sp, n
+
+    def free_kv_blocks(self):
+        """Blocks free in the pool right now (-1: the session has contiguous slots)."""
+        n, bs = self._C.c_int32(0), self._C.c_int32(0)
+        self._L.check(self._L.lib().vlg_gpt_session_free_blocks(self.model._handle, self._C.byref(n), self._C.byref(bs)))
+        return n.value
+
+    def _reserve(self, slot, r):
+        """True when the slot now owns KV blocks for the request; False = pool full, try again after a request has finished."""
+        rc = self._L.lib().vlg_gpt_session_reserve(self.model._handle, slot, int(r.params.max_tokens))
+        if rc == self._L.VLG_ERR_OOM:
+            self.deferred += 1
+            return False
+        self._L.check(rc)
+        return True
 
     def close(self):
         if self._open:
@@ -254,6 +277,12 @@ class ContinuousLLMEngine:
                 r = self.waiting[0]
                 if r.params.max_tokens > self.session_tokens:
                     raise ValueError("request %s asks for %d tokens, the session holds %d" % (r.request_id, r.params.max_tokens, self.session_tokens))
+                if self.cfg and not self.text and not self.pending_null:
+                    continue                                        # its null-class partner has not arrived yet
+                if not self._reserve(i, r):
+                    if not any(self.slots):
+                        raise ValueError("request %s does not fit the KV pool even when it is empty" % r.request_id)
+                    break                                           # FIFO: wait for blocks instead of overtaking
                 if self.text:
                     self.waiting.popleft()
                     dev = self.model._device
@@ -265,8 +294,6 @@ class ContinuousLLMEngine:
                     self.slots[i] = [r, 0, None]
                     row_class[i] = -3                               # first iteration: the last condition token, samples token 0
                     continue
-                if self.cfg and not self.pending_null:
-                    continue                                        # its null-class partner has not arrived yet
                 self.waiting.popleft()
                 partner = self.pending_null.popleft() if self.cfg else None
                 self.slots[i] = [r, 0, partner]
@@ -291,6 +318,7 @@ class ContinuousLLMEngine:
                 outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, toks)]))
                 if partner is not None:
                     outs.append(RequestOutput(partner.request_id, None, partner.prompt_token_ids, [CompletionOutput(0, list(toks))]))
+                L.check(L.lib().vlg_gpt_session_release(self.model._handle, i))
                 self.slots[i] = None
         if not self.has_unfinished_requests():
             self.close()
