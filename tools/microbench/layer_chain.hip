@@ -33,6 +33,18 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed, float scale) {
   }
 }
 
+// experiment: pull a weight matrix through the caches ahead of the kernel that uses it (plain loads, results folded into one dead store)
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n16, unsigned* sink) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned acc = 0;
+  for (; i < n16; i += stride) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
 static bf16* alloc_fill(size_t n, uint32_t seed, float scale) {
   bf16* p;
   CK(hipMalloc(&p, n * 2));
@@ -47,6 +59,9 @@ int main(int argc, char** argv) {
   const bool static_a = argc > 2 && atoi(argv[2]) == 1;   // experiment: prologue kernels read a never-written activation buffer
   const bool splitk = argc > 3 && atoi(argv[3]) == 1;     // in-launch split-K for the two residual GEMMs
   const bool stats = !(argc > 4 && atoi(argv[4]) == 0);   // residual-stream row statistics handed from producer to consumer (LDS-DMA kernel)
+  const int prefetch = argc > 5 ? atoi(argv[5]) : 0;      // 1: read each layer's weights right before its four kernels (warm MALL / L2)
+  unsigned* sink;
+  CK(hipMalloc(&sink, 4));
   float* rowsq = nullptr;
   CK(hipMalloc(&rowsq, (size_t)(1280 / 16 + 1) * 64 * sizeof(float)));
   CK(hipMemset(rowsq, 0, (size_t)(1280 / 16 + 1) * 64 * sizeof(float)));
@@ -89,6 +104,12 @@ int main(int argc, char** argv) {
   auto enqueue = [&](bool tr) {
     int k = 0;
     for (int l = 0; l < L; ++l) {
+      if (prefetch) {
+        prefetch_kernel<<<1024, 256, 0, st>>>((const uint4*)wqkv[l], (size_t)3 * D * D / 8, sink);
+        prefetch_kernel<<<1024, 256, 0, st>>>((const uint4*)wo[l], (size_t)D * D / 8, sink);
+        prefetch_kernel<<<1024, 256, 0, st>>>((const uint4*)w13[l], (size_t)2 * F * D / 8, sink);
+        prefetch_kernel<<<1024, 256, 0, st>>>((const uint4*)w2[l], (size_t)D * F / 8, sink);
+      }
       FusedGemm fa;
       fa.norm_w = nw1[l];
       fa.qbuf = q; fa.kc = kc; fa.vc = vc; fa.freqs = freqs; fa.state = state; fa.Tq = 1; fa.H = H; fa.hd = hd; fa.S = S;
