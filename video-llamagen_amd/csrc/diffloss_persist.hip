@@ -20,8 +20,11 @@
 // (input_proj, LayerNorm affine, biases of the workgroup's columns) live in LDS.  Rounding points are those of the launch chain
 // (gemm_ln_kernel / EPI_GATED / dl_step_proj_kernel), so both paths agree to fp32 summation order.
 // A poll that does not complete within its bound poisons the group's outputs with NaN and leaves (no hang).
-// Measured (tools/microbench/dl_persist_lab.hip, MI355X, 32 rows, W 1024, depth 3, bf16): 26.6 us per reverse step against ~65 us of
-// the launch chain; of those, 6 x ~2.3 us are the exchanges (store -> fabric -> load), 6 x 0.5 us the GEMMs, 4 x ~0.9 us LayerNorms.
+// Weights: a workgroup needs the same 32 columns of every matrix in all S steps.  With the depth known at compile time (3, the reference's)
+// the block loop is unrolled and the fragments of the first GEMM phases of a step stay in registers for the whole launch, one more phase's
+// in LDS; the rest is streamed from L2 per step, requested at the start of the exchange that precedes its GEMM.
+// Measured (tools/microbench/dl_persist_lab.hip, MI355X, 32 rows, W 1024, depth 3, bf16): 21.1 us per reverse step against ~65 us of
+// the launch chain; of those, 6 x 1.3-2.2 us are the exchanges (store -> fabric -> load), 6 x 0.5 us the GEMMs, 4 x 0.85 us LayerNorms.
 #include <type_traits>
 
 #include "gpt_kernels.h"
@@ -83,6 +86,9 @@ __device__ __forceinline__ float dp_wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+#ifndef VLG_DP_NRES2
+#define VLG_DP_NRES2 3   // register-resident GEMM phases at NKBW 2 (W 1024 bf16): 4 would spill
+#endif
 constexpr int DP_MAXKB = 4;   // K blocks (256 bytes of a row) per wave: W * sizeof(T) / 256 / 4 <= 4  (W <= 2048 bf16, 1024 fp32)
 
 template <typename T>
@@ -136,19 +142,22 @@ struct DpRaw<float> {
 // LDS carve-up (bytes), shared by the kernel and the launcher
 template <typename T>
 struct DpLds {
-  size_t hfull, afull, red, outs, xs, wip, bip, ln, bias, bfin, total;
-  __host__ __device__ DpLds(int W, int depth) {
+  size_t hfull, afull, red, outs, xs, cfs, wip, bip, ln, bias, bfin, wl, total;
+  __host__ __device__ DpLds(int W, int depth, int lds_phases = 0) {
     size_t o = 0;
     hfull = o; o += (size_t)DP_R * W * sizeof(T);
     afull = o; o += (size_t)DP_R * W * sizeof(T);
     red = o; o += 4 * 2 * 256 * sizeof(float);
     outs = o; o += DP_R * 16 * sizeof(float);
     xs = o; o += DP_R * 16 * sizeof(float);
+    cfs = o; o += 64 * 8 * sizeof(float);
     wip = o; o += (size_t)W * 8 * sizeof(float);
     bip = o; o += (size_t)W * sizeof(float);
     ln = o; o += (size_t)depth * 2 * W * sizeof(T);
     bias = o; o += (size_t)depth * 2 * DP_TC * sizeof(float);
     bfin = o; o += 16 * sizeof(float);
+    o = (o + 15) & ~(size_t)15;
+    wl = o; o += (size_t)lds_phases * 32768 * ((W * sizeof(T) + 1023) / 1024);   // fragments of GEMM phases kept in LDS: [2][NKBW][4][256 threads] x 16 B each
     total = o;
   }
 };
@@ -168,8 +177,15 @@ struct DpLds {
 // NKBW: K blocks (256 bytes of a row) per wave = 16-byte chunks of a row per lane = ceil(W * sizeof(T) / 1024)
 // FULL: W * sizeof(T) is a multiple of 1024, every wave / lane has exactly NKBW blocks / chunks (no guards: the compiler can count the
 // loads in flight and wait for the oldest only)
-template <typename T, int NKBW, bool FULL>
+// DEPTH > 0: the number of res blocks at compile time - the block loop is unrolled and the weight fragments of the first NRES GEMM
+// phases of a reverse step (w0[0], w2[0], w0[1], ...) stay in registers for the whole launch (a workgroup uses the same 32 columns of
+// every matrix in all S steps): no loads in front of those phases' polls, no wait behind them.  DEPTH = 0: runtime depth, all streamed.
+template <typename T, int NKBW, bool FULL, int DEPTH>
 __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
+  // 32 * NKBW VGPRs per resident phase: all 2 * DEPTH phases at NKBW 1, VLG_DP_NRES2 of them at NKBW 2 (W 1024 bf16; 4 would spill)
+  constexpr int NRES = (DEPTH == 0 || NKBW > 2) ? 0 : (NKBW == 1 ? (2 * DEPTH < 8 ? 2 * DEPTH : 8) : VLG_DP_NRES2);
+  // ... and the next NLDS phases keep their fragments in LDS (64 KB per phase at NKBW 2), read back per lane right before the GEMM
+  constexpr int NLDS = (NRES > 0 && NRES < 2 * DEPTH && NKBW == 2) ? 1 : 0;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int KBLK = 256 / (int)sizeof(T);
   const int W = p.W, C = p.C, S = p.S, MR = p.MR, depth = p.depth;
@@ -177,17 +193,19 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   const int nkb = W / KBLK;
   const int nch = W / EPV;                           // 16-byte chunks per activation row
   extern __shared__ __attribute__((aligned(16))) char dp_smem[];
-  const DpLds<T> L(W, depth);
+  const DpLds<T> L(W, depth, NLDS);
   T* hfull = reinterpret_cast<T*>(dp_smem + L.hfull);       // [R][W] residual stream of the group's rows
   T* afull = reinterpret_cast<T*>(dp_smem + L.afull);       // [R][W] current GEMM input (modulated LN output / mlp.0 output)
   float* red = reinterpret_cast<float*>(dp_smem + L.red);   // [4 waves][2 n-tiles][256]
   float* outs = reinterpret_cast<float*>(dp_smem + L.outs); // [R][16] final layer outputs (eps | v)
   float* xs = reinterpret_cast<float*>(dp_smem + L.xs);     // [R][16] current x_t rows (rounded to T)
+  float* cfs = reinterpret_cast<float*>(dp_smem + L.cfs);   // [64][8] this step's DDPM coefficients + noise draw per (row, channel) thread
   float* wip_s = reinterpret_cast<float*>(dp_smem + L.wip); // [W][8] input_proj.weight, zero padded beyond C
   float* bip_s = reinterpret_cast<float*>(dp_smem + L.bip); // [W]
   T* ln_s = reinterpret_cast<T*>(dp_smem + L.ln);           // [depth][weight | bias][W]
   float* bias_s = reinterpret_cast<float*>(dp_smem + L.bias); // [depth][mlp.0 | mlp.2][32] biases of this workgroup's columns
   float* bfin_s = reinterpret_cast<float*>(dp_smem + L.bfin); // [16] final layer bias
+  dp_u32x4_t* wl_s = reinterpret_cast<dp_u32x4_t*>(dp_smem + L.wl);   // [phase][2][NKBW][4][256 threads] fragments, each thread its own
   __shared__ int ok_sm;
 #ifdef VLG_DP_PROF
   __shared__ unsigned long long prof_s[16];
@@ -478,9 +496,39 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   __syncthreads();
 
   bool alive = true;
-  dp_u32x4_t bf[2][NKBW][4];     // hidden layers: two 16-column tiles
-  dp_u32x4_t bff[1][NKBW][4];    // final layer: one tile of 2C <= 16 outputs
-  load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
+  dp_u32x4_t bf[2][NKBW][4];     // hidden layers: two 16-column tiles (the streamed phases)
+  dp_u32x4_t bff[1][NKBW][4];    // final layer: one tile of 2C <= 16 outputs, resident
+  dp_u32x4_t wres[NRES > 0 ? NRES : 1][2][NKBW][4];
+  load_w(reinterpret_cast<const T*>(p.wf), 2 * C, 0, bff);
+  // fragments of an LDS-resident phase <-> bf
+  auto lds_put = [&](int slot) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < NKBW; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) wl_s[((((size_t)slot * 2 + nt) * NKBW + i) * 4 + s2) * 256 + tid] = bf[nt][i][s2];
+  };
+  auto lds_get = [&](int slot) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < NKBW; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) bf[nt][i][s2] = wl_s[((((size_t)slot * 2 + nt) * NKBW + i) * 4 + s2) * 256 + tid];
+  };
+  if constexpr (NRES > 0) {
+#pragma unroll
+    for (int ph = 0; ph < NRES; ++ph) load_w(reinterpret_cast<const T*>((ph & 1) ? p.w2[ph >> 1] : p.w0[ph >> 1]), W, col0, wres[ph]);
+#pragma unroll
+    for (int j = 0; j < NLDS; ++j) {
+      const int ph = NRES + j;
+      load_w(reinterpret_cast<const T*>((ph & 1) ? p.w2[ph >> 1] : p.w0[ph >> 1]), W, col0, bf);
+      lds_put(j);
+    }
+  } else {
+    load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
+  }
   // wave 0: this lane's two elements of the published [R][32] tile
   const int e0 = elem(0), e1 = elem(1);
   const int prow0 = e0 / DP_TC, pc0 = e0 % DP_TC, prow1 = e1 / DP_TC, pc1 = e1 % DP_TC;
@@ -489,76 +537,104 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     const T* mod = reinterpret_cast<const T*>(p.mod_all) + (size_t)(S - 1) * p.B * MR;
     prefetch_mod(vsc, vsh, mod, mod + W);
   }
+  // one res block (diffloss.py:99-129).  WA / WB: register-resident fragments of mlp.0 / mlp.2; SA / SB / SN: where mlp.0 / mlp.2 of this
+  // block / mlp.0 of the next block live - 0 registers, 1 streamed into `bf` (requested at the start of the preceding exchange), 2 LDS
+  auto res_block = [&](int blk, int k, int i, const T* mod, const auto& WA, const auto& WB, auto SA, auto SB, auto SN, DdpmCoef& cf, float& nz) {
+    const T* m0 = mod + (size_t)blk * 3 * W;          // [shift | scale | gate]  (diffloss.py:125)
+    if (blk == 1) DP_STAMP(12);
+    ln_modulate(ln_s + (size_t)(blk * 2) * W, ln_s + (size_t)(blk * 2 + 1) * W);
+    if (blk == 1) DP_STAMP(13);
+    __syncthreads();
+    if (blk == 0) DP_STAMP(1);
+    if (blk == 1) DP_STAMP(14);
+    if constexpr (decltype(SA)::value == 2) lds_get(2 * blk - NRES);
+    if constexpr (decltype(SA)::value != 0) gemm(bf);
+    else gemm(WA);
+    __syncthreads();
+    if (blk == 0) DP_STAMP(2);
+    epoch += 1;
+    if (wave == 0) {          // mlp.0: rt(silu(rt(acc + bias)))
+      const float v0 = dp_rt<T>(reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc0]);
+      const float v1 = dp_rt<T>(reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc1]);
+      publish(dp_silu(v0), dp_silu(v1));
+    }
+    if (blk == 0) DP_STAMP(3);
+    typename DpRaw<T>::type g0r = 0, g1r = 0;      // gate values as stored (converted where they are used, not where they are requested)
+    alive = collect(afull, [&]() {
+      if constexpr (decltype(SB)::value == 1) load_w(reinterpret_cast<const T*>(p.w2[blk]), W, col0, bf);   // in flight during the exchange
+      if (wave == 0) {
+        g0r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg0 * MR + 2 * W + col0 + pc0);
+        g1r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg1 * MR + 2 * W + col0 + pc1);
+        if (blk == 0) {
+          const int row = lane / 16, c = lane % 16;
+          if (c < C && row < nrow) {
+            cf = p.coef[i];
+            const int b = row0 + row;
+            nz = p.noise ? p.noise[(((size_t)step_tok * (S + 1) + 1 + k) * p.B_total + p.b_off + b) * C + c]
+                         : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, (uint32_t)(1 + k));
+          }
+        }
+      }
+    });
+    if (blk == 0) DP_STAMP(4);
+    if (!alive) return;
+    if (blk == 0 && wave == 0) {   // the step's coefficients and noise are in: park them in LDS, so that the DDPM update at the end of
+                                   // the step does not wait on whatever loads are in flight by then
+      float* o = cfs + lane * 8;
+      o[0] = cf.sqrt_recip; o[1] = cf.sqrt_recipm1; o[2] = cf.coef1; o[3] = cf.coef2; o[4] = cf.min_log; o[5] = cf.max_log;
+      o[6] = __int_as_float(cf.nonzero); o[7] = nz;
+    }
+    if constexpr (decltype(SB)::value == 2) lds_get(2 * blk + 1 - NRES);
+    if constexpr (decltype(SB)::value != 0) gemm(bf);
+    else gemm(WB);
+    __syncthreads();
+    if (blk == 0) DP_STAMP(5);
+    epoch += 1;
+    if (wave == 0) {          // mlp.2 + gate + residual: h = rt(h + rt(gate * rt(acc + bias)))   (diffloss.py:128)
+      const float v0 = reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc0];
+      const float v1 = reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc1];
+      const float h0 = DT<T>::ld(hfull + (size_t)prow0 * W + col0 + pc0), h1 = DT<T>::ld(hfull + (size_t)prow1 * W + col0 + pc1);
+      const float g0 = DpRaw<T>::f(g0r), g1 = DpRaw<T>::f(g1r);
+      publish(h0 + dp_rt<T>(g0 * dp_rt<T>(v0)), h1 + dp_rt<T>(g1 * dp_rt<T>(v1)));
+    }
+    if (blk == 0) DP_STAMP(6);
+    alive = collect(hfull, [&]() {
+      prefetch_mod(vsc, vsh, m0 + 3 * W, m0 + 4 * W);        // the next block's, or the final layer's, [shift | scale]
+      if (blk + 1 < depth) {
+        if constexpr (decltype(SN)::value == 1) load_w(reinterpret_cast<const T*>(p.w0[blk + 1]), W, col0, bf);
+      } else if (k + 1 < S) {
+        const T* mn = reinterpret_cast<const T*>(p.mod_all) + (size_t)(i - 1) * p.B * MR;
+        prefetch_mod(vsc2, vsh2, mn, mn + W);
+      }
+    });
+    if (blk == 0) DP_STAMP(7);
+    if (blk == 1) DP_STAMP(15);
+  };
   for (int k = 0; k < S && alive; ++k) {
     const int i = S - 1 - k;
     const T* mod = reinterpret_cast<const T*>(p.mod_all) + (size_t)i * p.B * MR;
     DP_STAMP(0);
     DdpmCoef cf{};     // this step's posterior coefficients and noise draw (threads of the DDPM update)
     float nz = 0.f;
-    for (int blk = 0; blk < depth && alive; ++blk) {
-      const T* m0 = mod + (size_t)blk * 3 * W;          // [shift | scale | gate]  (diffloss.py:125)
-      if (blk == 1) DP_STAMP(12);
-      ln_modulate(ln_s + (size_t)(blk * 2) * W, ln_s + (size_t)(blk * 2 + 1) * W);
-      if (blk == 1) DP_STAMP(13);
-      __syncthreads();
-      if (blk == 0) DP_STAMP(1);
-      if (blk == 1) DP_STAMP(14);
-      gemm(bf);
-      __syncthreads();
-      if (blk == 0) DP_STAMP(2);
-      epoch += 1;
-      if (wave == 0) {          // mlp.0: rt(silu(rt(acc + bias)))
-        const float v0 = dp_rt<T>(reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc0]);
-        const float v1 = dp_rt<T>(reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc1]);
-        publish(dp_silu(v0), dp_silu(v1));
-      }
-      if (blk == 0) DP_STAMP(3);
-      typename DpRaw<T>::type g0r = 0, g1r = 0;      // gate values as stored (converted where they are used, not where they are requested)
-      alive = collect(afull, [&]() {
-        load_w(reinterpret_cast<const T*>(p.w2[blk]), W, col0, bf);   // in flight during the exchange
-        if (wave == 0) {
-          g0r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg0 * MR + 2 * W + col0 + pc0);
-          g1r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg1 * MR + 2 * W + col0 + pc1);
-          if (blk == 0) {
-            const int row = lane / 16, c = lane % 16;
-            if (c < C && row < nrow) {
-              cf = p.coef[i];
-              const int b = row0 + row;
-              nz = p.noise ? p.noise[(((size_t)step_tok * (S + 1) + 1 + k) * p.B_total + p.b_off + b) * C + c]
-                           : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, (uint32_t)(1 + k));
-            }
-          }
-        }
-      });
-      if (blk == 0) DP_STAMP(4);
-      if (!alive) break;
-      gemm(bf);
-      __syncthreads();
-      if (blk == 0) DP_STAMP(5);
-      epoch += 1;
-      if (wave == 0) {          // mlp.2 + gate + residual: h = rt(h + rt(gate * rt(acc + bias)))   (diffloss.py:128)
-        const float v0 = reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc0];
-        const float v1 = reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc1];
-        const float h0 = DT<T>::ld(hfull + (size_t)prow0 * W + col0 + pc0), h1 = DT<T>::ld(hfull + (size_t)prow1 * W + col0 + pc1);
-        const float g0 = DpRaw<T>::f(g0r), g1 = DpRaw<T>::f(g1r);
-        publish(h0 + dp_rt<T>(g0 * dp_rt<T>(v0)), h1 + dp_rt<T>(g1 * dp_rt<T>(v1)));
-      }
-      if (blk == 0) DP_STAMP(6);
-      alive = collect(hfull, [&]() {
-        if (blk + 1 < depth) {
-          load_w(reinterpret_cast<const T*>(p.w0[blk + 1]), W, col0, bf);
-          prefetch_mod(vsc, vsh, m0 + 3 * W, m0 + 4 * W);
-        } else {
-          load_w(reinterpret_cast<const T*>(p.wf), 2 * C, 0, bff);
-          prefetch_mod(vsc, vsh, m0 + 3 * W, m0 + 4 * W);      // the final layer's [shift | scale]
-          if (k + 1 < S) {
-            const T* mn = reinterpret_cast<const T*>(p.mod_all) + (size_t)(i - 1) * p.B * MR;
-            prefetch_mod(vsc2, vsh2, mn, mn + W);
-          }
-        }
-      });
-      if (blk == 0) DP_STAMP(7);
-      if (blk == 1) DP_STAMP(15);
+    if constexpr (DEPTH == 0) {
+      for (int blk = 0; blk < depth && alive; ++blk) res_block(blk, k, i, mod, bf, bf, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cf, nz);
+    } else {
+      // unrolled: phase 2 * blk (mlp.0) and 2 * blk + 1 (mlp.2) are resident while < NRES
+#define DP_KIND(PH_) ((PH_) < NRES ? 0 : ((PH_) < NRES + NLDS ? 2 : 1))
+#define DP_BLOCK(B_)                                                                                                                    \
+  if constexpr ((B_) < DEPTH) {                                                                                                         \
+    if (alive)                                                                                                                          \
+      res_block((B_), k, i, mod, wres[(2 * (B_) < NRES) ? 2 * (B_) : 0], wres[(2 * (B_) + 1 < NRES) ? 2 * (B_) + 1 : 0],                \
+                std::integral_constant<int, DP_KIND(2 * (B_))>{}, std::integral_constant<int, DP_KIND(2 * (B_) + 1)>{},                 \
+                std::integral_constant<int, DP_KIND(2 * (B_) + 2)>{}, cf, nz);                                                          \
+  }
+      static_assert(DEPTH <= 4, "unrolled for up to 4 res blocks");
+      DP_BLOCK(0)
+      DP_BLOCK(1)
+      DP_BLOCK(2)
+      DP_BLOCK(3)
+#undef DP_BLOCK
+#undef DP_KIND
     }
     if (!alive) break;
     DP_STAMP(8);
@@ -574,9 +650,10 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       gemm(bff);
       __syncthreads();
       DP_STAMP(9);
-      // the next step's first weights: consumed after that step's LayerNorm (measured: requested before the last collect() instead,
-      // they sit in front of its polls and cost more than they hide)
-      if (k + 1 < S) load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
+      // streamed form: the next step's first weights, consumed after that step's LayerNorm (measured: requested before the last collect()
+      // instead, they sit in front of its polls and cost more than they hide)
+      if constexpr (NRES == 0)
+        if (k + 1 < S) load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
       if (tid < DP_R * 16) {
         const int row = tid / 16, c = tid % 16;
         float v = 0.f;
@@ -588,14 +665,15 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       if (tid < DP_R * 16) {
         const int row = tid / 16, c = tid % 16;
         if (c < C && row < nrow) {
+          const float* cs = cfs + tid * 8;       // {sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log, nonzero, noise} of this step
           const float eps = outs[row * 16 + c], v = outs[row * 16 + C + c];
           const float xv = xs[row * 16 + c];
           const float frac = (v + 1.0f) / 2.0f;
-          const float logvar = frac * cf.max_log + (1.0f - frac) * cf.min_log;
-          const float x0 = cf.sqrt_recip * xv - cf.sqrt_recipm1 * eps;
-          const float mean = cf.coef1 * x0 + cf.coef2 * xv;
+          const float logvar = frac * cs[5] + (1.0f - frac) * cs[4];
+          const float x0 = cs[0] * xv - cs[1] * eps;
+          const float mean = cs[2] * x0 + cs[3] * xv;
           float rr = mean;
-          if (cf.nonzero) rr = mean + expf(0.5f * logvar) * nz * p.temperature;
+          if (__float_as_int(cs[6]) != 0) rr = mean + expf(0.5f * logvar) * cs[7] * p.temperature;
           xs[row * 16 + c] = dp_rt<T>(rr);
         }
       }
@@ -632,22 +710,27 @@ template <typename T>
 bool dl_persist_ok(int B, int W, int C, int depth) {
   if (B < 1 || W < 256 || W % 256 != 0 || C < 1 || 2 * C > 16 || depth < 1 || depth > 8) return false;
   const int nkb = W * (int)sizeof(T) / 256;
-  return nkb <= 4 * DP_MAXKB && W / DP_TC <= 64 && DpLds<T>(W, depth).total <= 150 * 1024 &&
+  return nkb <= 4 * DP_MAXKB && W / DP_TC <= 64 && DpLds<T>(W, depth, 1).total <= 150 * 1024 &&
          cdiv(B, DP_R) * (W / DP_TC) <= 256;   // one workgroup per CU: every participant of an exchange is resident
 }
 template bool dl_persist_ok<float>(int, int, int, int);
 template bool dl_persist_ok<bf16>(int, int, int, int);
 
 namespace {
-template <typename T, int NKBW, bool FULL>
-int dp_launch(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
+template <typename T, int NKBW, bool FULL, int DEPTH>
+int dp_launch1(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dl_persist_kernel<T, NKBW, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dl_persist_kernel<T, NKBW, FULL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr = true;
   }
-  dl_persist_kernel<T, NKBW, FULL><<<grid, 256, lds, st>>>(p);
+  dl_persist_kernel<T, NKBW, FULL, DEPTH><<<grid, 256, lds, st>>>(p);
   return VLG_OK;
+}
+template <typename T, int NKBW, bool FULL>
+int dp_launch(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
+  if (p.depth == 3) return dp_launch1<T, NKBW, FULL, 3>(p, grid, lds, st);   // the reference's depth (gpt_video_diff.py:77): resident weights
+  return dp_launch1<T, NKBW, FULL, 0>(p, grid, lds, st);
 }
 }  // namespace
 
@@ -661,7 +744,9 @@ int dl_persist(const DlPersist& p, hipStream_t st) {
   VLG_HIP(hipMemsetAsync(p.xbuf, 0, dl_persist_xbuf_bytes(p.B, p.W, (int)sizeof(T)), st));   // epoch tags count within the launch
   // LDS: the activations plus padding up to > 80 KB so that no two workgroups share a CU (table row 1 of the hand-off forms is measured
   // for one workgroup per CU; correctness does not depend on it, the exchange latency does)
-  size_t lds = DpLds<T>(p.W, p.depth).total;
+  const int nkbw0 = cdiv(p.W * (int)sizeof(T) / 256, 4);
+  const int lds_phases = (p.depth == 3 && nkbw0 == 2 && VLG_DP_NRES2 > 0 && VLG_DP_NRES2 < 6) ? 1 : 0;   // = NLDS of the kernel that will run
+  size_t lds = DpLds<T>(p.W, p.depth, lds_phases).total;
   if (lds < 96 * 1024) lds = 96 * 1024;
   const int nkbw = cdiv(p.W * (int)sizeof(T) / 256, 4);
   const bool full = (p.W * (int)sizeof(T)) % 1024 == 0 && nkbw != 3;
