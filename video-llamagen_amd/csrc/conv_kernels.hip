@@ -249,15 +249,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const T* __r
 // patch pitch (18 rows) away and half of the tap offsets are 2-way conflicts.
 constexpr int HT_TW = 32, HT_HW = HT_TW + 2;
 constexpr int HT_MAXROWS = (2 + 2) * (4 + 2) * HT_HW;          // 816 patch positions at kt = 3, tile 2 x 4 x 32 (1 x 10 x 34 = 340 for images)
-constexpr int HT_SLOTS = (HT_MAXROWS * 4 + 511) / 512;         // 16-byte chunks per thread per patch: 6
+template <int NTHR>
+constexpr int ht_slots() { return (HT_MAXROWS * 4 + NTHR - 1) / NTHR; }   // 16-byte chunks per thread per patch: 7 at 512 threads, 13 at 256
 constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) * sizeof(uint4);   // 2 patches + 2 x 3 weight taps
 
 // T = bf16: 32-channel chunks, v_mfma_f32_32x32x16_bf16.  T = float (the reference runs the VQ-16 decoder in fp32): 16-channel
 // chunks - the same 64-byte patch rows and LDS image - on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak instead of a direct conv).
-template <typename T, int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
-__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
-                                                        const float* __restrict__ bias, const T* __restrict__ residual,
-                                                        T* __restrict__ out_cl, float* __restrict__ out_planar) {
+// NWM: 32-row MFMA blocks per wave along the positions.  2: 8 waves (4 x 2), each 64 x 64 - 32 FLOP per LDS byte, exactly the CU's
+// LDS : MFMA balance.  4: 4 waves (2 x 2), each 128 x 64 - every B fragment feeds 4 MFMAs instead of 2, 25 % fewer LDS bytes per FLOP.
+template <typename T, int HT_TT, int HT_TH, int NWM = 2>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
+__global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+                                                               const float* __restrict__ bias, const T* __restrict__ residual,
+                                                               T* __restrict__ out_cl, float* __restrict__ out_planar) {
+  constexpr int NTHR = 1024 / NWM;           // 512 / 256 threads
+  constexpr int HT_SLOTS = ht_slots<NTHR>();
+  constexpr int WPT = 512 / NTHR;            // weight chunks per thread per tap: 128 rows x 4 chunks over the workgroup
   constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int KC = 4 * EPV;                // channels per chunk step: one 64-byte patch row
   static_assert(HT_TT * HT_TH * HT_TW == 256, "256 positions per tile");
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   const int t0 = (bid % nTt) * HT_TT;
   const int b = bid / nTt;
 
-  // patch gather roles: chunk e = tid + 512 k  ->  patch row e >> 2, 16-byte chunk e & 3
+  // patch gather roles: chunk e = tid + NTHR k  ->  patch row e >> 2, 16-byte chunk e & 3
   const int HF = HT_TT + d.kt - 1;
   const int nrows = HF * HT_HH * HT_HW;
   const int He = d.Hi << d.up, We = d.Wi << d.up;
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   int hslot[HT_SLOTS];
 #pragma unroll
   for (int k = 0; k < HT_SLOTS; ++k) {
-    const int e = tid + 512 * k;
+    const int e = tid + NTHR * k;
     const int hr = e >> 2, ch = e & 3;
     hoff[k] = -2;
     hslot[k] = 0;
@@ -328,20 +334,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
 
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
-  const int wrow = tid >> 2, wch = tid & 3;
+  const int wrow = tid >> 2, wch = tid & 3;       // (+ 64 rows for the second chunk of a 256-thread workgroup)
   const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
-  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));
+  const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
+  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
   const int cin8 = d.Cin / EPV;   // 16-byte chunks per (cout, tap) weight row
   const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
   const int Q = ncc * rows_per_chunk;
   int l_row = 0, l_cc = 0;   // load iterator: two steps ahead of the MFMAs
-  uint4 wrA0, wrA1, wrA2, wrB0, wrB1, wrB2;   // two register sets as scalars (hipcc leaves uint4 arrays swapped between roles in scratch)
-  wrA0 = wrA1 = wrA2 = wrB0 = wrB1 = wrB2 = make_uint4(0, 0, 0, 0);
+  // two register sets as scalars (hipcc leaves uint4 arrays swapped between roles in scratch); 3..5 only with 256 threads
+  uint4 wrA0, wrA1, wrA2, wrA3, wrA4, wrA5, wrB0, wrB1, wrB2, wrB3, wrB4, wrB5;
+  wrA0 = wrA1 = wrA2 = wrA3 = wrA4 = wrA5 = wrB0 = wrB1 = wrB2 = wrB3 = wrB4 = wrB5 = make_uint4(0, 0, 0, 0);
 #define w_gload(wr)                                                                   \
   do {                                                                                \
     wr##0 = wbase[(size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];                         \
     wr##1 = wbase[(size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];                         \
     wr##2 = wbase[(size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];                         \
+    if constexpr (WPT == 2) {                                                         \
+      wr##3 = wbase[wrow2 + (size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];               \
+      wr##4 = wbase[wrow2 + (size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];               \
+      wr##5 = wbase[wrow2 + (size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];               \
+    }                                                                                 \
     if (++l_row == rows_per_chunk) {                                                  \
       l_row = 0;                                                                      \
       if (++l_cc == ncc) l_cc = 0; /* past the end: reload a valid tile, unused */    \
@@ -353,18 +366,23 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     wb_[0 * 512 + wslot] = wr##0;              \
     wb_[1 * 512 + wslot] = wr##1;              \
     wb_[2 * 512 + wslot] = wr##2;              \
+    if constexpr (WPT == 2) {                  \
+      wb_[0 * 512 + 256 + wslot] = wr##3;      \
+      wb_[1 * 512 + 256 + wslot] = wr##4;      \
+      wb_[2 * 512 + 256 + wslot] = wr##5;      \
+    }                                          \
   } while (0)
 
   // fragment roles
-  int hb[2];
+  int hb[NWM];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = wave_m * 64 + mi * 32 + r32;
+  for (int mi = 0; mi < NWM; ++mi) {
+    const int m = wave_m * (32 * NWM) + mi * 32 + r32;
     hb[mi] = ((m >> TSH) * HT_HH + ((m >> 5) & (HT_TH - 1))) * HT_HW + (m & 31);
   }
-  f32x16_t acc[2][2];
+  f32x16_t acc[NWM][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < NWM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -375,9 +393,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        uint4 af[2], bfr[2];
+        uint4 af[NWM], bfr[2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < NWM; ++mi) {
           const int row = hb[mi] + toff + j;
           af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
         }
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
         }
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < NWM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]),
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < NWM; ++mi)
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&af[mi].x)[e]), __uint_as_float((&bfr[ni].x)[e]),
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   // epilogue: + bias (+ residual) -> channels-last bf16 or planar fp32
   const long long pper = (long long)d.To * d.Ho * d.Wo;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < NWM; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int co = n0 + wave_n * 64 + ni * 32 + r32;
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       float rv[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = wave_m * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int m = wave_m * (32 * NWM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
         pe[e] = (t < d.To && y < d.Ho && x < d.Wo) ? (((long long)b * d.To + t) * d.Ho + y) * d.Wo + x : -1;
       }
@@ -571,13 +589,13 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
   {
     static const bool halo_off = getenv("VLG_CONV_HALO") != nullptr && atoi(getenv("VLG_CONV_HALO")) == 0;   // A/B knob
     if (!halo_off && conv_halo_ok(d, sizeof(T) == 2 ? 32 : 16)) {
+      static const int nwm = getenv("VLG_CONV_NWM") ? atoi(getenv("VLG_CONV_NWM")) : 2;   // A/B knob: 4 = four waves of 128 x 64
       static bool attr_set = false;   // per instantiation of conv_forward<T>
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)HT_LDS_BYTES);
-        if (e == hipSuccess)
-          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)HT_LDS_BYTES);
+        hipError_t e = hipSuccess;
+        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2>),
+                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 4>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 4>)})
+          if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_LDS_BYTES);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
           return VLG_ERR_HIP;
@@ -599,12 +617,16 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       } stop{(e0 && e1) ? e1 : nullptr, st};
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
         const long long tiles = (long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<T, 1, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
-                                                                                                              out_planar);
+        if (nwm == 4)
+          conv_halo_kernel<T, 1, 8, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else
+          conv_halo_kernel<T, 1, 8, 2><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       } else {
         const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<T, 2, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl,
-                                                                                                             out_planar);
+        if (nwm == 4)
+          conv_halo_kernel<T, 2, 4, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else
+          conv_halo_kernel<T, 2, 4, 2><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       }
       return VLG_OK;
     }

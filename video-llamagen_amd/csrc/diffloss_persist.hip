@@ -706,12 +706,25 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 
 size_t dl_persist_xbuf_bytes(int B, int W, int esz) { return (size_t)2 * cdiv(B, DP_R) * (W / DP_TC) * (DP_R * DP_TC * esz / 4) * 8; }
 
+namespace {
+// compute units of the current device: every workgroup of the launch must be resident at once (they wait for each other), and each takes a
+// whole CU (LDS >= 96 KB)
+int dp_cu_count() {
+  static int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+  }();
+  return n;
+}
+}  // namespace
+
 template <typename T>
 bool dl_persist_ok(int B, int W, int C, int depth) {
   if (B < 1 || W < 256 || W % 256 != 0 || C < 1 || 2 * C > 16 || depth < 1 || depth > 8) return false;
   const int nkb = W * (int)sizeof(T) / 256;
   return nkb <= 4 * DP_MAXKB && W / DP_TC <= 64 && DpLds<T>(W, depth, 1).total <= 150 * 1024 &&
-         cdiv(B, DP_R) * (W / DP_TC) <= 256;   // one workgroup per CU: every participant of an exchange is resident
+         cdiv(B, DP_R) * (W / DP_TC) <= dp_cu_count();   // one workgroup per CU: every participant of an exchange is resident
 }
 template bool dl_persist_ok<float>(int, int, int, int);
 template bool dl_persist_ok<bf16>(int, int, int, int);
