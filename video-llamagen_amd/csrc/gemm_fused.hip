@@ -124,8 +124,12 @@ __device__ __forceinline__ void mfma_one(const u32x4_t& a, const u32x4_t& b, f32
   }
 }
 
-template <typename T, int MT, int NW, bool PRO, int EPI>
+// NC: output columns per workgroup.  8 (EPI_RESID at M <= 16 only): lanes 8..15 of a 16-lane group mirror lanes 0..7 (same weight row,
+// same column, results dropped) - half of the MFMA tile is wasted, but twice the workgroups stream the two N = D matrices, whose 80
+// 16-column tiles leave 2/3 of the CUs idle while each busy one is bound by its own miss-handling rate.
+template <typename T, int MT, int NW, bool PRO, int EPI, int NC = 16>
 __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, FusedGemm fa) {
+  static_assert(NC == 16 || (NC == 8 && EPI == EPI_RESID && !PRO), "8-column tiles: residual epilogue only");
   constexpr int KBLK = KB<T>::KBLK;
   constexpr int NH = (EPI == EPI_SWIGLU) ? 2 : 1;
   constexpr int NB = (MT * NH >= 4) ? 2 : 4;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     bx = (id & 7) + 8 * (id >> 4);
     by = (id >> 3) & 1;
   }
-  const int n0 = bx * 16, m0 = by * (MT * 16);
+  const int n0 = bx * NC, m0 = by * (MT * 16);
   const int nkb = K / KBLK;
   const int split = blockIdx.z, splits = gridDim.z;   // > 1 only for !PRO kernels (host-enforced)
   VLG_KT(0);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
 
   const T* wrow[NH];
 #pragma unroll
-  for (int hf = 0; hf < NH; ++hf) wrow[hf] = w + (size_t)(n0 + r + (NH == 2 ? hf * N : 0)) * K;
+  for (int hf = 0; hf < NH; ++hf) wrow[hf] = w + (size_t)(n0 + (r & (NC - 1)) + (NH == 2 ? hf * N : 0)) * K;
   const T* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   // (HBM), then the epilogue operands that do not depend on the GEMM (residual rows; RoPE pair of the current position).  The
   // norm prologue then runs on the activations while the weights are still in flight, and the epilogue never waits on memory.
   const int et = threadIdx.x, ee = et >> 6, el = et & 63;
-  const int ecol = n0 + (el & 15);
+  const int ecol = n0 + (el & (NC - 1));
   float eres[MT], ecx[MT], ecy[MT];   // ecx doubles as the gate value for EPI_GATED
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   VLG_KT(2);
   const int t = threadIdx.x;
   const int e = t >> 6, l2 = t & 63;
-  const int col = n0 + (l2 & 15);
+  const int col = n0 + (l2 & (NC - 1));
   float part[MT];
   if constexpr (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE)) {
     if (splits > 1) {
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       }
     }
     if (row >= M) continue;
+    if (NC == 8 && (l2 & 8)) continue;   // mirror lanes
     if constexpr (EPI == EPI_RESID) {
       DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(s0));
     } else if constexpr (EPI == EPI_GATED) {
@@ -1032,6 +1037,16 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
   }
   const bool wide = (mt * nh >= 4) || (rows16 && cdiv(nkb_all, splits) > 16);   // 8 waves so one pass of the K loop covers the slice
   dim3 grid(N / 16, cdiv(M, mt * 16), splits);
+  // small batches (M <= 16: the per-GPU shards of a batch split over GPUs): the two N = D GEMMs on 8-column tiles, twice the workgroups
+  static const int nc8_knob = lds_knob("VLG_GEMM_NC8", 1);
+  if (nc8_knob && !pro && epi == EPI_RESID && M <= 16 && splits == 1 && !fa.sq_out && N / 16 <= 128 && N % 8 == 0) {
+    grid = dim3(N / 8, 1, 1);
+    if (nkb_all > 16)
+      gemm_fused_kernel<T, 1, 8, false, EPI_RESID, 8><<<grid, 512, 0, st>>>(x, w, M, N, K, fa);
+    else
+      gemm_fused_kernel<T, 1, 4, false, EPI_RESID, 8><<<grid, 256, 0, st>>>(x, w, M, N, K, fa);
+    return VLG_OK;
+  }
 #define VLG_GF(MT_, NW_)                                                            \
   do {                                                                              \
     if (pro)                                                                        \
