@@ -568,6 +568,17 @@ def test_full_width_decode_paths_agree():
     m.fuse_gemm = False
     f = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
     assert torch.isfinite(e).all() and (e[:, :3] - f[:, :3]).abs().max().item() < 3e-2 * max(scale, e.abs().max().item())
+    # small shards (4 and 12 rows: what one GPU holds when 32 videos are split over 8 / odd splits): the N = D GEMMs run on 8-column
+    # tiles there (gemm_fused_kernel<..., NC = 8>, 160 workgroups) - against the slab path on the same rows
+    for rows in (4, 12):
+        m.fuse_gemm = True
+        g8 = V.generate_t2v(m, cond[:rows], 24, mask[:rows])
+        assert torch.isfinite(g8).all() and torch.equal(g8, V.generate_t2v(m, cond[:rows], 24, mask[:rows]))
+        m.fuse_gemm = False
+        s8 = V.generate_t2v(m, cond[:rows], 24, mask[:rows])
+        sc8 = max(1.0, s8.abs().max().item())
+        assert torch.equal(g8[:, 0], s8[:, 0]) and (g8[:, :3] - s8[:, :3]).abs().max().item() < 2e-2 * sc8, rows
+    m.fuse_gemm = True
 
 
 def test_generate_edge_shapes():
