@@ -869,11 +869,13 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int HD>
+// NS: partials requested up front (8 for nsplit <= 8; 16 for the deeper splits of small batches, where this launch is as long as the
+// attention kernel itself if it walks the partials one dependent load at a time)
+template <typename T, int HD, int NS>
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int nsplit) {
   const size_t mh = blockIdx.x;
   const float* base = ws + mh * nsplit * (HD + 2);
-  constexpr int NS = 8, ND = (HD + 63) / 64;
+  constexpr int ND = (HD + 63) / 64;
   if (nsplit <= NS) {
     // every partial this thread needs is requested before the first use: one memory round trip instead of three
     float mv[NS], lv[NS], av[NS][ND];
@@ -970,7 +972,12 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
                                                                                          Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
-  if (nsplit > 1 && counters == nullptr) attn_combine_kernel<T, HD><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+  if (nsplit > 1 && counters == nullptr) {
+    if (nsplit <= 8)
+      attn_combine_kernel<T, HD, 8><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+    else
+      attn_combine_kernel<T, HD, 16><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+  }
   return VLG_OK;
 }
 
