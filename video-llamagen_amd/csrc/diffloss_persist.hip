@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   float* outs = reinterpret_cast<float*>(dp_smem + L.outs); // [R][16] final layer outputs (eps | v)
   float* xs = reinterpret_cast<float*>(dp_smem + L.xs);     // [R][16] current x_t rows (rounded to T)
   float* cfs = reinterpret_cast<float*>(dp_smem + L.cfs);   // [64][8] this step's DDPM coefficients + noise draw per (row, channel) thread
-  float* wip_s = reinterpret_cast<float*>(dp_smem + L.wip); // [W][8] input_proj.weight, zero padded beyond C
+  float* wip_s = reinterpret_cast<float*>(dp_smem + L.wip); // [8][W] input_proj.weight transposed, zero rows beyond C
   float* bip_s = reinterpret_cast<float*>(dp_smem + L.bip); // [W]
   T* ln_s = reinterpret_cast<T*>(dp_smem + L.ln);           // [depth][weight | bias][W]
   float* bias_s = reinterpret_cast<float*>(dp_smem + L.bias); // [depth][mlp.0 | mlp.2][32] biases of this workgroup's columns
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   {
     const T* wip = reinterpret_cast<const T*>(p.wip);
     const T* bip = reinterpret_cast<const T*>(p.bip);
-    for (int e = tid; e < W * 8; e += 256) {
-      const int w = e >> 3, c = e & 7;
+    for (int e = tid; e < W * 8; e += 256) {   // transposed: the 8 columns a lane projects sit side by side for every input channel
+      const int c = e / W, w = e - c * W;
       wip_s[e] = c < C ? DT<T>::ld(wip + (size_t)w * C + c) : 0.f;
     }
     for (int e = tid; e < W; e += 256) bip_s[e] = DT<T>::ld(bip + e);
@@ -257,44 +257,6 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   }
 
   // ---- helpers ------------------------------------------------------------------------------------------------------------
-  // y[row][w] = rt(bias[w] + sum_c xs[row][c] * wip[w][c]) -> hfull   (diffloss.py:226); xs and wip_s are zero beyond C
-  auto input_proj = [&]() {
-    float xr[DP_R][8];
-#pragma unroll
-    for (int row = 0; row < DP_R; ++row) {
-      const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16 + 4);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xr[row][c] = a[c];
-        xr[row][4 + c] = b[c];
-      }
-    }
-    for (int w = 2 * tid; w < W; w += 512) {          // two adjacent columns per thread: one 4-byte (bf16) / 8-byte (fp32) LDS store per row
-      float wv[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(wip_s + (size_t)(w + u) * 8);
-        const dp_f32x4_t b = *reinterpret_cast<const dp_f32x4_t*>(wip_s + (size_t)(w + u) * 8 + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          wv[u][c] = a[c];
-          wv[u][4 + c] = b[c];
-        }
-      }
-      const float bb0 = bip_s[w], bb1 = bip_s[w + 1];
-#pragma unroll
-      for (int row = 0; row < DP_R; ++row) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          a0 = fmaf(xr[row][c], wv[0][c], a0);
-          a1 = fmaf(xr[row][c], wv[1][c], a1);
-        }
-        if constexpr (sizeof(T) == 2) *reinterpret_cast<unsigned*>(hfull + (size_t)row * W + w) = dp_pack2(a0 + bb0, a1 + bb1);
-        else *reinterpret_cast<dp_f2_t*>(hfull + (size_t)row * W + w) = dp_f2_t{a0 + bb0, a1 + bb1};
-      }
-    }
-  };
   // Loads that leave the chip's caches (this table, the gate rows, the step's noise) are issued right before a collect() and consumed
   // after it: collect() waits for its own loads, which return after every older one, so nothing else in the step waits on memory.
   dp_u32x4_t vsc[NKBW], vsh[NKBW];       // rows of the next LayerNorm
@@ -314,15 +276,55 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   };
   // afull = rt(rt(LN(hfull) [* lnw + lnb]) * (1 + scale) + shift); one wave per row, the row in registers, two-pass statistics like
   // dl_ln_modulate_kernel / gemm_ln_kernel
-  auto ln_modulate = [&](const T* lnw, const T* lnb) {
+  // FROMX (the first LayerNorm of a reverse step): the row is not read from hfull but computed here from the step's x_t -
+  // h[w] = rt(bias[w] + sum_c x[c] * wip[w][c])  (input_proj, diffloss.py:226; xs and wip_s are zero beyond C) - and stored to hfull
+  // for the residual adds: no separate projection pass, no barrier between it and the statistics
+  auto ln_modulate = [&](const T* lnw, const T* lnb, auto FROMX) {
     const int row = wave;
     float hv[NKBW][EPV];
     float s = 0.f;
+    float xr[8];
+    if constexpr (decltype(FROMX)::value) {
+      const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16 + 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        xr[c] = a[c];
+        xr[4 + c] = b[c];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NKBW; ++it) {
       const int c = lane + 64 * it;
       if (FULL || c < nch) {
-        dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(hfull + (size_t)row * W)[c], hv[it]);
+        if constexpr (decltype(FROMX)::value) {
+          float acc[EPV];
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {          // channel-major: fmaf chain per element in channel order, as dl_step_proj_kernel
+            float wv[EPV];
+#pragma unroll
+            for (int v4 = 0; v4 < EPV / 4; ++v4) {
+              const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(wip_s + (size_t)cc * W + (size_t)c * EPV + 4 * v4);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) wv[4 * v4 + u] = t4[u];
+            }
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) acc[j] = fmaf(xr[cc], wv[j], acc[j]);
+          }
+          float bb[EPV];
+#pragma unroll
+          for (int v4 = 0; v4 < EPV / 4; ++v4) {
+            const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(bip_s + (size_t)c * EPV + 4 * v4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bb[4 * v4 + u] = t4[u];
+          }
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) hv[it][j] = dp_rt<T>(acc[j] + bb[j]);
+          reinterpret_cast<dp_u32x4_t*>(hfull + (size_t)row * W)[c] = dp_pack<T>(hv[it]);
+        } else {
+          dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(hfull + (size_t)row * W)[c], hv[it]);
+        }
 #pragma unroll
         for (int j = 0; j < EPV; ++j) s += hv[it][j];
       }
@@ -492,8 +494,6 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     xs[tid] = v;
   }
   __syncthreads();
-  input_proj();
-  __syncthreads();
 
   bool alive = true;
   dp_u32x4_t bf[2][NKBW][4];     // hidden layers: two 16-column tiles (the streamed phases)
@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   auto res_block = [&](int blk, int k, int i, const T* mod, const auto& WA, const auto& WB, auto SA, auto SB, auto SN, DdpmCoef& cf, float& nz) {
     const T* m0 = mod + (size_t)blk * 3 * W;          // [shift | scale | gate]  (diffloss.py:125)
     if (blk == 1) DP_STAMP(12);
-    ln_modulate(ln_s + (size_t)(blk * 2) * W, ln_s + (size_t)(blk * 2 + 1) * W);
+    if (blk == 0) ln_modulate(ln_s, ln_s + W, std::true_type{});
+    else ln_modulate(ln_s + (size_t)(blk * 2) * W, ln_s + (size_t)(blk * 2 + 1) * W, std::false_type{});
     if (blk == 1) DP_STAMP(13);
     __syncthreads();
     if (blk == 0) DP_STAMP(1);
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     DP_STAMP(8);
     // final layer (diffloss.py:141-148): modulate(LN(h)) -> Linear W -> 2C, computed by every workgroup for its rows
     {
-      ln_modulate(nullptr, nullptr);
+      ln_modulate(nullptr, nullptr, std::false_type{});
 #pragma unroll
       for (int it = 0; it < NKBW; ++it) {
         vsc[it] = vsc2[it];
@@ -654,19 +655,12 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       // instead, they sit in front of its polls and cost more than they hide)
       if constexpr (NRES == 0)
         if (k + 1 < S) load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
-      if (tid < DP_R * 16) {
-        const int row = tid / 16, c = tid % 16;
-        float v = 0.f;
-        if (c < 2 * C) v = dp_rt<T>(reduced(0, row, c) + bfin_s[c]);
-        outs[tid] = v;
-      }
-      __syncthreads();
       // p_sample (gaussian_diffusion.py:254-332,376-420): learned-range variance, eps prediction, clip_denoised = False
       if (tid < DP_R * 16) {
         const int row = tid / 16, c = tid % 16;
         if (c < C && row < nrow) {
           const float* cs = cfs + tid * 8;       // {sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log, nonzero, noise} of this step
-          const float eps = outs[row * 16 + c], v = outs[row * 16 + C + c];
+          const float eps = dp_rt<T>(reduced(0, row, c) + bfin_s[c]), v = dp_rt<T>(reduced(0, row, C + c) + bfin_s[C + c]);   // final layer outputs (eps | v)
           const float xv = xs[row * 16 + c];
           const float frac = (v + 1.0f) / 2.0f;
           const float logvar = frac * cs[5] + (1.0f - frac) * cs[4];
@@ -679,10 +673,6 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       }
       __syncthreads();
       DP_STAMP(10);
-      if (k + 1 < S) {
-        input_proj();
-        __syncthreads();
-      }
       DP_STAMP(11);
     }
   }
