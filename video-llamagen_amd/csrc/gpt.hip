@@ -537,12 +537,29 @@ struct Runner {
   bool fused_decode_ok() {
     const int D = h->D, F = h->F;
     if (!h->fuse_gemm || h->hd % 2 != 0) return false;
-    bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_fused_ok<T>(Bp, D, D, false, EPI_RESID) &&
-              gemm_fused_ok<T>(Bp, F, D, true, EPI_SWIGLU) && gemm_fused_ok<T>(Bp, D, F, false, EPI_RESID);
-    if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, true, EPI_STORE);
-    if (h->cfg.head == VLG_HEAD_ADAPTER2) ok = ok && gemm_fused_ok<T>(Bp, D, D, true, EPI_STORE);
-    if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, true, EPI_STORE);
+    // pro = false: only the tiling has to fit.  Where the in-kernel RMSNorm prologue does not cover the width (K * elem > 4 KB or more K
+    // blocks than one pass holds: GPT-3B, D 3200) norm_gemm() runs the norm as its own launch in front of the same kernel.
+    static const int nopro_rows = getenv("VLG_FUSED_NOPRO_ROWS") ? atoi(getenv("VLG_FUSED_NOPRO_ROWS")) : 32;
+    const bool pro = Bp > nopro_rows;   // beyond that many rows the 64 x 64 slab GEMMs win (measured: GPT-3B, 64 rows, 2.58 vs 3.27 s)
+    bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, pro, EPI_QKV) && gemm_fused_ok<T>(Bp, D, D, false, EPI_RESID) &&
+              gemm_fused_ok<T>(Bp, F, D, pro, EPI_SWIGLU) && gemm_fused_ok<T>(Bp, D, F, false, EPI_RESID);
+    if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, pro, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_ADAPTER2) ok = ok && gemm_fused_ok<T>(Bp, D, D, pro, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, pro, EPI_STORE);
     return ok;
+  }
+  // y = epilogue(RMSNorm(x; norm_w) @ w^T): one launch with the norm as the GEMM's prologue, or norm + GEMM where the prologue does not
+  // cover K (same rounding points: the explicit kernel is the slab path's, xn rounded to T either way)
+  int norm_gemm(T* x, const T* norm_w, const T* w, int Nn, int K, int epi, FusedGemm& fa) {
+    fa.eps = h->cfg.norm_eps;
+    if (gemm_fused_ok<T>(Bp, Nn, K, true, epi)) {
+      fa.norm_w = norm_w;
+      return gemm_fused<T>(x, w, Bp, Nn, K, true, epi, fa, st);
+    }
+    VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, norm_w, ln->xn.as<T>(), Bp, K, h->cfg.norm_eps, st));
+    fa.norm_w = nullptr;
+    fa.sq_in = nullptr;
+    return gemm_fused<T>(ln->xn.as<T>(), w, Bp, Nn, K, false, epi, fa, st);
   }
 
   // x [Bp, D] = residual stream (token / latent embeddings); on return x holds the last layer's output, NOT normed
@@ -567,8 +584,6 @@ struct Runner {
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
       T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
       FusedGemm fa;
-      fa.norm_w = W<T>(p + "attention_norm.weight");
-      fa.eps = h->cfg.norm_eps;
       fa.qbuf = ln->q.as<T>();
       fa.kc = kc;
       fa.vc = vc;
@@ -586,7 +601,7 @@ struct Runner {
         fa.sq_tiles = D / 16;
         fa.sq_stride = sq_stride;
       }
-      VLG_TRY(gemm_fused<T>(x, W<T>(p + "attention.wqkv.weight"), M, 3 * D, D, true, EPI_QKV, fa, st));
+      VLG_TRY(norm_gemm(x, W<T>(p + "attention_norm.weight"), W<T>(p + "attention.wqkv.weight"), 3 * D, D, EPI_QKV, fa));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
@@ -608,8 +623,6 @@ struct Runner {
       }
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
-      fs.norm_w = W<T>(p + "ffn_norm.weight");
-      fs.eps = h->cfg.norm_eps;
       fs.out = ln->g.as<T>();
       fs.lds = h->gemm_lds;
       if (stats) {
@@ -617,7 +630,7 @@ struct Runner {
         fs.sq_tiles = D / 16;
         fs.sq_stride = sq_stride;
       }
-      VLG_TRY(gemm_fused<T>(x, W<T>(p + "feed_forward.w13"), M, F, D, true, EPI_SWIGLU, fs, st));
+      VLG_TRY(norm_gemm(x, W<T>(p + "ffn_norm.weight"), W<T>(p + "feed_forward.w13"), F, D, EPI_SWIGLU, fs));
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
     }
     x_has_stats = stats;
@@ -628,8 +641,7 @@ struct Runner {
   int head_fused(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
     FusedGemm fa;
-    fa.norm_w = W<T>("norm.weight");
-    fa.eps = h->cfg.norm_eps;
+    const T* final_norm = W<T>("norm.weight");
     fa.lds = h->gemm_lds;
     if (x_has_stats) {
       fa.sq_in = ln->rowsq.as<float>();
@@ -639,14 +651,14 @@ struct Runner {
     x_has_stats = false;
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       fa.out_f32 = ln->logits.as<float>();
-      VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("output.weight"), Bp, h->V, D, true, EPI_STORE, fa, st));
+      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("output.weight"), h->V, D, EPI_STORE, fa));
       return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
                          ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot, row_step);
     }
     if (h->cfg.head == VLG_HEAD_ADAPTER2) {
       fa.out = ln->t1.as<T>();
       fa.act = ACT_GELU_TANH;
-      VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("vae_latent_adapter2.fc1.weight"), Bp, D, D, true, EPI_STORE, fa, st));
+      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("vae_latent_adapter2.fc1.weight"), D, D, EPI_STORE, fa));
       if (h->C <= 16)   // fc2 (N = C) + CFG combine + stores in one launch (3 before)
         return latent_out_fc2<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter2.fc2.weight"), ln->cur_lat.as<float>(),
                                  out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, D, N, sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
@@ -657,7 +669,7 @@ struct Runner {
     // hidden (DiffLoss): cond_embed(norm(x)) is the first op of the head (diffloss.py:227)
     fa.out = ln->d_cemb.as<T>();
     fa.bias = W<T>("diffloss.net.cond_embed.bias");
-    VLG_TRY(gemm_fused<T>(ln->x.as<T>(), W<T>("diffloss.net.cond_embed.weight"), Bp, h->dW, D, true, EPI_STORE, fa, st));
+    VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("diffloss.net.cond_embed.weight"), h->dW, D, EPI_STORE, fa));
     return diffloss_head(nullptr, sp, noise, out_lat, trace);
   }
 
