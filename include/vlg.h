@@ -142,6 +142,11 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto:
  * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
+/* real-valued options.  "cfg_iter" (default 1.0; hidden / DiffLoss head only): the `cfg` argument of DiffLoss.sample
+ * (autoregressive/models/diffloss.py:35-41 -> SimpleMLPAdaLN.forward_with_cfg :240-248, passed as cfg_iter by generate_video_diff.py:89-91):
+ * != 1 treats rows [0, B/2) of the batch as the conditional and rows [B/2, B) as the unconditional half of every pair (b, b + B/2): one
+ * x_T draw per pair, the network sees the conditional half's x_t twice, eps = u + cfg (c - u); B must be even.                        */
+int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value);
 /* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last
  * call and replays it while shape, sampling parameters, options and buffer addresses are unchanged                           */
 int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count);

@@ -448,15 +448,29 @@ class DiffLossOracle:
         g = rt(rt(layer_norm(h), dt) * (F32(1) + scale) + shift, dt)
         return self.lin(g, "final_layer.linear")
 
-    def sample(self, z, noise, temperature=1.0):
-        """z [B,D]; noise [S+1,B,C]: noise[0] = x_T, noise[1+k] = draw of the k-th reverse step (k = 0 is t = S-1)."""
+    def sample(self, z, noise, temperature=1.0, cfg=1.0):
+        """z [B,D]; noise [S+1,B,C]: noise[0] = x_T, noise[1+k] = draw of the k-th reverse step (k = 0 is t = S-1).
+        cfg != 1 (diffloss.py:37-41,240-248): rows [0, B/2) are the conditional half, rows [B/2, B) the unconditional one; x_T of row b
+        is noise[0][b % (B/2)]; the network sees the conditional half's x_t twice, eps is combined, every row keeps its own variance,
+        draws and x_t recursion."""
         sc = self.sched
         S = len(sc["timestep_map"])
-        x = rt(noise[0], self.dt)
+        B = z.shape[0]
+        n = B // 2
+        if cfg != 1.0:
+            assert B % 2 == 0 and B > 0
+            x = rt(np.concatenate([noise[0][:n], noise[0][:n]], 0), self.dt)
+        else:
+            x = rt(noise[0], self.dt)
         C = x.shape[1]
         for k, i in enumerate(range(S - 1, -1, -1)):
-            out = self.net(x, np.full((x.shape[0],), sc["timestep_map"][i]), z).astype(F32)
+            xin = x if cfg == 1.0 else np.concatenate([x[:n], x[:n]], 0)
+            out = self.net(xin, np.full((x.shape[0],), sc["timestep_map"][i]), z).astype(F32)
             eps, v = out[:, :C], out[:, C:]
+            if cfg != 1.0:
+                ce, ue = eps[:n], eps[n:]
+                he = rt(ue + rt(F32(cfg) * rt(ce - ue, self.dt), self.dt), self.dt)
+                eps = np.concatenate([he, he], 0)
             frac = (v + F32(1)) / F32(2)                                                  # gaussian_diffusion.py:288-290
             logvar = frac * F32(sc["max_log"][i]) + (F32(1) - frac) * F32(sc["min_log"][i])
             x0 = F32(sc["sqrt_recip"][i]) * x - F32(sc["sqrt_recipm1"][i]) * eps            # :334-339 (clip_denoised=False)
@@ -466,9 +480,9 @@ class DiffLossOracle:
         return x
 
 
-def generate_t2v_diff(model, head, cond, max_new_tokens, emb_masks, noise, temperature=1.0):
+def generate_t2v_diff(model, head, cond, max_new_tokens, emb_masks, noise, temperature=1.0, cfg_iter=1.0):
     """generate_video_diff.py:185-228 with cfg_scale = 1 (the only mode the shipped code runs), batched:
-    token = DiffLoss.sample(h[:, -1]).  noise [N, S+1, B, C]."""
+    token = DiffLoss.sample(h[:, -1], temperature, cfg_iter).  noise [N, S+1, B, C]."""
     assert model.model_type == "t2v" and model.head == "hidden"
     T, B = cond.shape[1], cond.shape[0]
     model.setup_caches(B, T + max_new_tokens)
@@ -476,11 +490,11 @@ def generate_t2v_diff(model, head, cond, max_new_tokens, emb_masks, noise, tempe
     C = model.cfg["vae_embed_dim"]
     out = np.empty((B, max_new_tokens, C), F32)
     z = model.forward(cond=cond, input_pos=np.arange(T))[:, -1]
-    e = head.sample(z, noise[0], temperature)
+    e = head.sample(z, noise[0], temperature, cfg_iter)
     out[:, 0] = e
     for i in range(max_new_tokens - 1):
         z = model.forward(latent=e[:, None, :], input_pos=np.array([T + i]))[:, -1]
-        e = head.sample(z, noise[i + 1], temperature)
+        e = head.sample(z, noise[i + 1], temperature, cfg_iter)
         out[:, i + 1] = e
     return out
 

@@ -428,6 +428,29 @@ def gold_t2vdiff(out):
     x = t(cases.rng(52).standard_normal((3, C), dtype=np.float32))
     z = t(cases.rng(53).standard_normal((3, cfg["dim"]), dtype=np.float32))
     out["net_out"] = m.diffloss.net(x, torch.tensor([999, 444, 0]), z).numpy()
+    # DiffLoss.sample with guidance inside the sampler (diffloss.py:37-41 -> forward_with_cfg :240-248) in isolation: z rows [cond | uncond],
+    # one x_T draw per pair (torch.randn(n, C)), then one torch.randn_like(x) per reverse step for all 2n rows
+    n_pair = 2
+    zc = cases.rng(54).standard_normal((2 * n_pair, cfg["dim"]), dtype=np.float32)
+    nz = cases.rng(56).standard_normal((S + 1, 2 * n_pair, C), dtype=np.float32)
+    calls2 = [0]
+
+    def nxt2(shape):
+        k = calls2[0]
+        calls2[0] += 1
+        a = t(nz[k][:n_pair] if k == 0 else nz[k])
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape, k)
+        return a.clone()
+
+    torch.randn = lambda *shape, **kw: nxt2(shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape)
+    torch.randn_like = lambda x, **kw: nxt2(x.shape)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            out["dlcfg_latents"] = m.diffloss.sample(t(zc), 0.9, 2.5).float().numpy()
+    finally:
+        torch.randn, torch.randn_like, torch.Tensor.cuda = orig_randn, orig_like, orig_cuda
+    assert calls2[0] == S + 1
     gd100 = gvd.DiffLoss(target_channels=8, z_channels=16, depth=1, width=16, num_sampling_steps="100").gen_diffusion
     out["sched100_timestep_map"] = np.array(gd100.timestep_map, np.int64)
     out["sched100_coef2"] = gd100.posterior_mean_coef2

@@ -420,9 +420,23 @@ def test_diffloss_head_vs_reference_golden(golden):
     b = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=11)
     d = V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), seed=12)
     assert torch.equal(a, b) and not torch.equal(a, d) and torch.isfinite(a).all()
+    # guidance inside the sampler (DiffLoss.sample cfg, forward_with_cfg): rows (b, b + B/2) are (cond, uncond) pairs.  Oracle pinned by the
+    # reference's DiffLoss.sample golden (t2vdiff.npz dlcfg_latents, tests/test_oracle_golden.py); 4 rows = 2 pairs, graph and eager
+    B = 4
+    noise = cases.rng(58).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7])
+    refg = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.8, cfg_iter=1.8)
+    refn = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.8)
+    assert np.abs(refg - refn).max() > 1e-2 * np.abs(refn).max()
+    for graph in (True, False):
+        m.use_graph = graph
+        latg = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.8, cfg_iter=1.8, noise=torch.from_numpy(noise))
+        assert np.abs(to_np(latg) - refg).max() < 1e-3 * max(1.0, np.abs(refg).max()), graph
+    latn = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.8, noise=torch.from_numpy(noise))   # and back
+    assert np.abs(to_np(latn) - refn).max() < 1e-3 * max(1.0, np.abs(refn).max())
     from video_llamagen_amd import _lib
     with pytest.raises(_lib.VlgError):
-        V.generate_t2v(m, torch.from_numpy(c), 4, torch.from_numpy(mk), cfg_iter=2.0)
+        V.generate_t2v(m, torch.from_numpy(c[:3]), 4, torch.from_numpy(mk[:3]), cfg_iter=2.0)          # odd batch: no pairs
 
 
 def test_diffloss_head_bf16_and_100_steps():

@@ -188,6 +188,13 @@ def test_diffloss_head(golden):
     lat = O.generate_t2v_diff(m, head, c, N, mk, noise, temperature=0.9)
     ref = g["t2vdiff_latents"]
     assert lat.shape == ref.shape == (1, N, C)
+    # guidance inside the sampler: the reference's DiffLoss.sample(z, 0.9, cfg=2.5) in isolation on 2 (cond, uncond) pairs
+    zc = cases.rng(54).standard_normal((4, cfg["dim"]), dtype=np.float32)
+    nz = cases.rng(56).standard_normal((S + 1, 4, C), dtype=np.float32)
+    refc = g["dlcfg_latents"]
+    outc = head.sample(zc, nz, 0.9, 2.5)
+    assert np.abs(outc - refc).max() < 1e-5 * np.abs(refc).max()
+    assert np.abs(head.sample(zc, nz, 0.9, 1.0) - refc).max() > 1e-2 * np.abs(refc).max()      # the guidance is not a no-op on this case
     assert np.abs(lat - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
 
 

@@ -174,35 +174,49 @@ template int dl_ddpm_step<bf16>(bf16*, const bf16*, const float*, const StepStat
 
 // One launch per reverse step: x_out = (k < 0 ? x_T : p_sample(x_in, net_out)), then the next network evaluation's input
 // projection hc[b][w] = rt(bias[w] + sum_c x_out[b][c] * Wip[w][c]) (diffloss.py:226, K = C <= 16).  One workgroup per row.
+// n_half > 0: guidance inside the sampler (DiffLoss.sample cfg != 1 -> SimpleMLPAdaLN.forward_with_cfg, diffloss.py:37-41,240-248): rows
+// [0, n_half) are the conditional half, [n_half, 2 n_half) the unconditional one.  x_T of row b is the draw of row b % n_half; the network
+// input of EVERY row is the conditional half's x_t (hc[b] = proj(x[b % n_half])); eps = rt(u + rt(cfg * rt(c - u))) for both rows of a
+// pair; variance, draws and the x_t recursion stay per row.
 template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void dl_step_proj_kernel(const T* __restrict__ x_in, T* __restrict__ x_out, const T* __restrict__ out,
                                                            const float* __restrict__ noise, const StepState* __restrict__ state, DdpmCoef cf, int k,
                                                            int S, int B, int C, int b_off, int B_total, float temperature, uint64_t seed,
-                                                           const T* __restrict__ wip, const T* __restrict__ bip, T* __restrict__ hc, int W) {
+                                                           const T* __restrict__ wip, const T* __restrict__ bip, T* __restrict__ hc, int W,
+                                                           int n_half, float cfg) {
   __shared__ float xs[CMAX];
   const int b = blockIdx.x, c = threadIdx.x, step = state->step;
-  if (c < C) {   // one thread per latent channel draws / steps; the row's values are shared through LDS
+  auto reverse_step = [&](int row) -> float {   // x_{t-1}[row][c] (or x_T for k < 0), rounded to T
+    const int pr = n_half ? row % n_half : row;
     float r;
     if (k < 0) {
-      r = noise ? noise[(((size_t)step * (S + 1)) * B_total + b_off + b) * C + c]
-                : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + b), (uint32_t)step, 0u);
+      r = noise ? noise[(((size_t)step * (S + 1)) * B_total + b_off + pr) * C + c]
+                : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + pr), (uint32_t)step, 0u);
     } else {
-      const float eps = DT<T>::ld(out + (size_t)b * 2 * C + c), v = DT<T>::ld(out + (size_t)b * 2 * C + C + c);
-      const float xv = DT<T>::ld(x_in + (size_t)b * C + c);
+      float eps = DT<T>::ld(out + (size_t)row * 2 * C + c);
+      if (n_half) {
+        const float ce = DT<T>::ld(out + (size_t)pr * 2 * C + c), ue = DT<T>::ld(out + (size_t)(pr + n_half) * 2 * C + c);
+        eps = DT<T>::rt(ue + DT<T>::rt(cfg * DT<T>::rt(ce - ue)));
+      }
+      const float v = DT<T>::ld(out + (size_t)row * 2 * C + C + c);
+      const float xv = DT<T>::ld(x_in + (size_t)row * C + c);
       const float frac = (v + 1.0f) / 2.0f;
       const float logvar = frac * cf.max_log + (1.0f - frac) * cf.min_log;
       const float x0 = cf.sqrt_recip * xv - cf.sqrt_recipm1 * eps;
       const float mean = cf.coef1 * x0 + cf.coef2 * xv;
       r = mean;
       if (cf.nonzero) {
-        const float n = noise ? noise[(((size_t)step * (S + 1) + 1 + k) * B_total + b_off + b) * C + c]
-                              : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + b), (uint32_t)step, (uint32_t)(1 + k));
+        const float n = noise ? noise[(((size_t)step * (S + 1) + 1 + k) * B_total + b_off + row) * C + c]
+                              : philox_normal(seed, (uint32_t)c, (uint32_t)(b_off + row), (uint32_t)step, (uint32_t)(1 + k));
         r = mean + expf(0.5f * logvar) * n * temperature;
       }
     }
-    r = DT<T>::rt(r);
-    xs[c] = r;
+    return DT<T>::rt(r);
+  };
+  if (c < C) {   // one thread per latent channel draws / steps; the row's values are shared through LDS
+    const float r = reverse_step(b);
     DT<T>::st(x_out + (size_t)b * C + c, r);
+    xs[c] = (n_half && b >= n_half) ? reverse_step(b - n_half) : r;   // the next evaluation reads the conditional half's x_t
   }
   if (hc == nullptr) return;
   __syncthreads();
@@ -216,19 +230,20 @@ __global__ __launch_bounds__(256) void dl_step_proj_kernel(const T* __restrict__
 }
 template <typename T>
 int dl_step_proj(const T* x_in, T* x_out, const T* out, const float* noise, const StepState* state, const DdpmCoef& cf, int k, int S, int B, int C,
-                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st) {
+                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st, int n_half,
+                 float cfg) {
   if (C > 16) {
     set_error("dl_step_proj: vae_embed_dim %d > 16", C);
     return VLG_ERR_UNSUPPORTED;
   }
   dl_step_proj_kernel<T, 16><<<B, 256, 0, st>>>(x_in, x_out, out, noise, state, cf, k, S, B, C, b_off, B_total, temperature, seed,
-                                                               wip, bip, hc, W);
+                                                               wip, bip, hc, W, n_half, cfg);
   return VLG_OK;
 }
 template int dl_step_proj<float>(const float*, float*, const float*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int,
-                                 float, uint64_t, const float*, const float*, float*, int, hipStream_t);
+                                 float, uint64_t, const float*, const float*, float*, int, hipStream_t, int, float);
 template int dl_step_proj<bf16>(const bf16*, bf16*, const bf16*, const float*, const StepState*, const DdpmCoef&, int, int, int, int, int, int, float,
-                                uint64_t, const bf16*, const bf16*, bf16*, int, hipStream_t);
+                                uint64_t, const bf16*, const bf16*, bf16*, int, hipStream_t, int, float);
 
 // sampled latent T [B,C] -> cur [B,C] fp32 (next step's input), out_lat[b][step], trace
 template <typename T>

@@ -63,6 +63,7 @@ struct vlg_gpt {
   DevBuf dcoef_dev;                  // DdpmCoef[S] on the device (persistent sampler)
   int kv_block = 0;                  // sessions: positions per KV block (0 = one contiguous slot of max length per row)
   int kv_pool_blocks = 0;            //           blocks in the pool, scratch block included (0 = enough for every row at full length)
+  float cfg_iter = 1.0f;             // DiffLoss.sample's cfg (generate_video_diff.py:89-91): != 1 pairs rows b and b + B/2 inside the sampler
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
@@ -700,6 +701,7 @@ struct Runner {
   // z = hl [B, D] (normed hidden of the last position).  All S steps are enqueued (and graph-captured) back to back.
   int diffloss_head(const T* z, const vlg_sampling_params& sp, const float* noise, float* out_lat, float* trace) {
     if (diffloss_fused_ok()) return diffloss_head_fused(z, sp, noise, out_lat, trace);
+    VLG_CHECK(h->cfg_iter == 1.0f, VLG_ERR_UNSUPPORTED, "cfg_iter != 1: the unfused DiffLoss sampler (option fuse_gemm = 0 / widths the fused GEMM does not tile) has no guidance");
     const int Wd = h->dW, C = h->C, dd = h->dDepth, S = h->dS, MR = (3 * dd + 2) * Wd;
     const std::string p = "diffloss.net.";
     T* cemb = ln->d_cemb.as<T>();
@@ -766,7 +768,13 @@ struct Runner {
     const T* wip = W<T>(p + "input_proj.weight");
     const T* bip = W<T>(p + "input_proj.bias");
     // one lane only: two persistent launches on concurrent branches could each hold half of the CUs and wait for the other half
-    if (h->dl_persist_on && h->last_lanes == 1 && dl_persist_ok<T>(B, Wd, C, dd)) {
+    const bool dcfg = h->cfg_iter != 1.0f;   // forward_with_cfg: the launch chain below (the persistent kernel keeps rows independent)
+    const int n_half = dcfg ? B / 2 : 0;
+    if (dcfg && (B % 2 != 0 || h->last_lanes != 1)) {
+      set_error("cfg_iter != 1 pairs row b with row b + B/2 (diffloss.py:38-39): it needs an even batch on one lane, got %d rows", B);
+      return VLG_ERR_BAD_SHAPE;
+    }
+    if (h->dl_persist_on && !dcfg && h->last_lanes == 1 && dl_persist_ok<T>(B, Wd, C, dd)) {
       // all S reverse steps in one persistent launch (2 depth all-gathers per step between the workgroups of a 4-row group)
       DlPersist dp{};
       for (int blk = 0; blk < dd; ++blk) {
@@ -798,7 +806,8 @@ struct Runner {
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
     const bool ln_in_gemm = gemm_ln_fused_ok<T>(B, Wd, Wd) && gemm_ln_fused_ok<T>(B, 2 * C, Wd) && !getenv("VLG_DIFFLOSS_NO_LN_FUSE");
     DdpmCoef none{};
-    VLG_TRY(dl_step_proj<T>(xb, xa, nullptr, noise, state(), none, -1, S, B, C, b0, Btot, sp.temperature, sp.seed, wip, bip, hc, Wd, st));
+    VLG_TRY(dl_step_proj<T>(xb, xa, nullptr, noise, state(), none, -1, S, B, C, b0, Btot, sp.temperature, sp.seed, wip, bip, hc, Wd, st, n_half,
+                            h->cfg_iter));
     for (int k = 0; k < S; ++k) {
       const int i = S - 1 - k;
       const T* mod = mod_all + (size_t)i * B * MR;
@@ -851,7 +860,7 @@ struct Runner {
       T* xin = (k & 1) ? xb : xa;
       T* xout = (k & 1) ? xa : xb;
       VLG_TRY(dl_step_proj<T>(xin, xout, dout, noise, state(), h->dcoef[i], k, S, B, C, b0, Btot, sp.temperature, sp.seed, wip, bip,
-                              k + 1 < S ? hc : nullptr, Wd, st));
+                              k + 1 < S ? hc : nullptr, Wd, st, n_half, h->cfg_iter));
     }
     const T* xfin = (S & 1) ? xb : xa;
     return dl_finish<T>(xfin, ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * C, trace, state(), B, C, N, b0, Btot, st);
@@ -1126,7 +1135,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->fuse_qkv ? 4 : 0) | (h->attn_inlaunch ? 8 : 0) |
-                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0) | (h->dl_persist_on ? 128 : 0)), (uint64_t)(uintptr_t)h->dcoef_dev.p};
+                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0) | (h->dl_persist_on ? 128 : 0)), (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter)};
       for (auto& r : rs) {
         key.push_back((uint64_t)(uintptr_t)r.st);
         const auto pk = r.ln->ptr_key();
@@ -1431,6 +1440,18 @@ extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* 
   VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
   h->ses->pos[slot] = -1;   // whatever ran in the slot is over: the caller reuses it (its tokens were read with session_read)
   return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
+}
+
+extern "C" int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value) {
+  VLG_CHECK(h && key, VLG_ERR_BAD_ARG, "vlg_gpt_set_option_f64: null argument");
+  if (!strcmp(key, "cfg_iter")) {
+    VLG_CHECK(value > 0.0 && value < 1e4, VLG_ERR_BAD_ARG, "cfg_iter %g out of range", value);
+    VLG_CHECK(value == 1.0 || h->cfg.head == VLG_HEAD_HIDDEN, VLG_ERR_UNSUPPORTED, "cfg_iter is the DiffLoss head's guidance (hidden head only)");
+    h->cfg_iter = (float)value;
+    return VLG_OK;
+  }
+  set_error("vlg_gpt_set_option_f64: unknown key %s", key);
+  return VLG_ERR_BAD_ARG;
 }
 
 extern "C" int vlg_gpt_session_reserve(vlg_gpt_t* h, int32_t slot, int32_t n_tokens) {

@@ -181,7 +181,8 @@ int dl_make_y_all(const T* temb, const T* cemb, T* ys, int S, int B, int W, hipS
 // x_out = x_T (k < 0) or p_sample(x_in, out) (k >= 0); hc = input_proj(x_out) when hc != null.  x_in != x_out.
 template <typename T>
 int dl_step_proj(const T* x_in, T* x_out, const T* out, const float* noise, const StepState* state, const DdpmCoef& cf, int k, int S, int B, int C,
-                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st);
+                 int b_off, int B_total, float temperature, uint64_t seed, const T* wip, const T* bip, T* hc, int W, hipStream_t st,
+                 int n_half = 0, float cfg = 1.0f);   // n_half > 0: guidance inside the sampler (forward_with_cfg), rows [cond | uncond]
 template <typename T>
 int dl_ln_modulate(const T* h, const T* lnw, const T* lnb, const T* shift, const T* scale, int mod_stride, T* g, int B, int W, hipStream_t st);
 template <typename T>

@@ -19,7 +19,7 @@ def _params(cfg_scale, cfg_interval, temperature=1.0, top_k=0, top_p=1.0, sample
                             seed=int(seed))
 
 
-def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, trace, sampling_kwargs):
+def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, trace, sampling_kwargs, cfg_iter=1.0):
     model._ensure_handle()
     dev = model._device
     B = cond.shape[0]
@@ -68,6 +68,8 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"attn_inlaunch", C.c_int64(1 if model.attn_inlaunch else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"gemm_lds", C.c_int64(1 if getattr(model, "gemm_lds", False) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(1 if getattr(model, "dl_persist", True) else 0)))
+        if latent and model._head_code() == L.VLG_HEAD_HIDDEN:
+            L.check(L.lib().vlg_gpt_set_option_f64(model._handle, b"cfg_iter", C.c_double(float(cfg_iter))))
         L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
                                          C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
                                          L.stream_ptr(dev)))
@@ -90,10 +92,11 @@ def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg
                  cfg_iter=1.0, **sampling_kwargs):
     """Continuous-latent generate (generate_video_diff.py:185-228): returns float [B, N, vae_embed_dim].
     head 'adapter2': token = vae_latent_adapter2(h) (gpt_video.py:431); head 'hidden': token = DiffLoss.sample(h, temperature,
-    cfg_iter) (generate_video_diff.py:89-91,132-134) - `noise` [N, steps+1, B, C] N(0,1) draws make it reproducible."""
+    cfg_iter) (generate_video_diff.py:89-91,132-134) - `noise` [N, steps+1, B, C] N(0,1) draws make it reproducible.  cfg_iter != 1 is
+    DiffLoss.sample's own guidance (diffloss.py:37-41): rows [0, B/2) conditional, [B/2, B) unconditional, B even."""
     if model.model_type != 't2v':
         raise Exception("please check model type")          # generate_video_diff.py:196
-    if cfg_iter != 1.0:
-        raise L.VlgError(-3, "cfg_iter != 1.0 (DiffLoss.forward_with_cfg) is not supported; the reference's scripts run cfg 1")
-    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs)
+    if cfg_iter != 1.0 and model._head_code() != L.VLG_HEAD_HIDDEN:
+        raise L.VlgError(-3, "cfg_iter is DiffLoss.sample's guidance: hidden head only")
+    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs, cfg_iter)
     return (out, tr) if return_trace else out
