@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=538.0,
                     help="an extra run starts only if the process would still be younger than this when it ends (the driver stops the default run at 600 s)")
     ap.add_argument("--hidden-tokens", type=int, default=256, help="tokens of the short DiffLoss-head run")
-    ap.add_argument("--lanes", type=int, default=0, help="batch lanes inside generate (0 = auto)")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="batch lanes inside generate (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of HIP-graph replay")
     ap.add_argument("--attn-inlaunch", action="store_true", help="merge the split-KV partials inside the attention launch (slower)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)

@@ -139,7 +139,7 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "fuse_qkv" (0: RoPE + KV append inside attention),
  * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "dl_persist" (1: DiffLoss sampler
  * as one persistent launch per token), "kv_block" / "kv_pool_blocks" (sessions, see above), "gemm_lds" (0: decode GEMMs
- * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto:
+ * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto, 1 or 2:
  * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
 /* real-valued options.  "cfg_iter" (default 1.0; hidden / DiffLoss head only): the `cfg` argument of DiffLoss.sample

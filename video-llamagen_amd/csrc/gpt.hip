@@ -422,7 +422,9 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     return VLG_OK;
   }
   if (!strcmp(key, "lanes")) {
-    VLG_CHECK(value >= 0 && value <= 4, VLG_ERR_BAD_ARG, "lanes must be 0 (auto) .. 4");
+    // at most 2: more lanes never paid off, and the HIP runtime (7.0 / 7.2) crashes in hip::Graph::UpdateStreams when a
+    // graph with more parallel branches than an earlier graph of the process is launched (2 -> 4 lanes on one handle)
+    VLG_CHECK(value >= 0 && value <= 2, VLG_ERR_BAD_ARG, "lanes must be 0 (auto), 1 or 2");
     h->lanes_opt = (int)value;
     return VLG_OK;
   }
@@ -1045,7 +1047,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   int nl = h->lanes_opt;
   if (nl <= 0) nl = 1;   // auto: measured on MI355X (r01): kernels of two lanes do not overlap enough to pay for streaming the weights twice
   if (nl > B) nl = B;
-  if (nl > 4) nl = 4;
+  if (nl > 2) nl = 2;
   while ((int)h->lanes.size() < nl) h->lanes.emplace_back(new Lane());
   const bool latent_out = h->cfg.head != VLG_HEAD_LOGITS;
   const size_t out_bytes = latent_out ? (size_t)B * N * h->C * sizeof(float) : (size_t)B * N * sizeof(int32_t);
