@@ -325,6 +325,8 @@ def main():
             roof_done = True
         else:
             step()
+        if rank == 0:   # a progress line per step on stderr (a silent 9-minute run looks hung to a watchdog); no synchronisation added
+            log(f"[bench] warm-up step {w + 1}/{a.warmup} enqueued at {elapsed():.0f} s")
         if w == 0 and cpu_child is not None:
             cpu_child.stdin.write("go\n")
             cpu_child.stdin.flush()
@@ -343,8 +345,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         step()
+        if rank == 0:
+            log(f"[bench] step {i + 1}/{a.steps} enqueued at {elapsed():.0f} s")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
