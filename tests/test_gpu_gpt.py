@@ -453,8 +453,8 @@ def test_diffloss_head_bf16_and_100_steps():
     assert np.abs(lat[:, 0] - ref[:, 0]).max() < 8e-2 * max(1.0, np.abs(ref[:, 0]).max())
 
 
-def _diff_model_w(dtype, width, steps):
-    cfg = dict(cases.TINY_T2V_DIFF, num_sampling_steps=steps, diffloss_w=width)
+def _diff_model_w(dtype, width, steps, depth=3):
+    cfg = dict(cases.TINY_T2V_DIFF, num_sampling_steps=steps, diffloss_w=width, diffloss_d=depth)
     import video_llamagen_amd as V
     keys = ("dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "caption_dim", "vae_embed_dim",
             "num_frames", "t_downsample_size", "head", "diffloss_w", "diffloss_d", "num_sampling_steps")
@@ -496,6 +496,33 @@ def test_diffloss_persistent_sampler_vs_oracle_and_launch_chain(B):
     m.dl_persist = False
     b = V.generate_t2v(m, torch.from_numpy(c), 3, torch.from_numpy(mk), seed=5)
     assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("width,depth", [(512, 3), (256, 2), (768, 3), (512, 4)])
+def test_diffloss_persistent_sampler_kernel_variants(width, depth):
+    """The other instantiations of the persistent sampler against the oracle and the launch chain (fp32): W 512 = one K block per wave with
+    every GEMM phase's fragments resident; depth 2 / 4 = the runtime-depth form (all phases streamed); W 768 = K blocks not a multiple of the
+    four waves (guarded loads).  5 rows = one full group + one row."""
+    import video_llamagen_amd as V
+    m, cfg, sd = _diff_model_w(torch.float32, width, 10, depth)
+    C, N, S, B = cfg["vae_embed_dim"], 3, 10, 5
+    noise = cases.rng(63).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1])
+    om = O.GPTOracle(cfg, sd, "fp32")
+    ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=1.0)
+    out = {}
+    for persist in (True, False):
+        m.dl_persist = persist
+        out[persist] = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+        assert np.isfinite(out[persist]).all(), persist
+        assert np.abs(out[persist] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), persist
+    assert np.abs(out[True] - out[False]).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    mb, _, _ = _diff_model_w(torch.bfloat16, width, 10, depth)
+    a = V.generate_t2v(mb, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise))
+    assert torch.isfinite(a).all() and torch.equal(a, V.generate_t2v(mb, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+    mb.dl_persist = False
+    b = V.generate_t2v(mb, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise))
+    assert (a[:, 0] - b[:, 0]).abs().max().item() < 8e-2 * max(1.0, b[:, 0].abs().max().item())
 
 
 def test_diffloss_persistent_sampler_bf16_full_width():

@@ -271,6 +271,33 @@ def test_block_granular_kv_sessions_vs_reference_golden(golden):
     assert (run_t(e) == g["t2i_fp32_cfg_ids"]).all()
 
 
+def test_block_granular_kv_is_the_same_arithmetic():
+    """Paging only changes where a cache row lives: sampled (top-k, temperature 1, guidance) bf16 sessions produce the same ids on 16-position
+    blocks handed out of a tight pool as on contiguous slots."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    cfg = cases.TINY_C2I
+    m, _ = product_gpt(cfg, torch.bfloat16)
+    N = cfg["block_size"]
+    labels = [int(c) for c in cases.class_ids(5, cfg["num_classes"])]
+    sp = V.SamplingParams(temperature=1.0, top_k=50, max_tokens=N, seed=11)
+
+    def run(**kw):
+        e = V.ContinuousLLMEngine(m, cfg_scale=2.0, max_num_seqs=4, max_tokens=N, **kw)
+        for i, c in enumerate(labels + [cfg["num_classes"]] * 5):
+            e.add_request(str(i), None, sp, [c])
+        outs = {}
+        while e.has_unfinished_requests():
+            for o in e.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+        return [outs[i] for i in range(5)], e
+
+    a, _ = run()
+    b, eng = run(kv_block_size=16, num_kv_blocks=1 + 2 * 2 * 2)      # 2 slots' worth of blocks (2 rows x 2 blocks each) for 2 running pairs
+    assert a == b
+
+
 def test_block_granular_kv_error_paths():
     import ctypes as C
     import video_llamagen_amd as V
