@@ -255,7 +255,8 @@ constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) *
 
 // T = bf16: 32-channel chunks, v_mfma_f32_32x32x16_bf16.  T = float (the reference runs the VQ-16 decoder in fp32): 16-channel
 // chunks - the same 64-byte patch rows and LDS image - on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak instead of a direct conv).
-// NWM: 32-row MFMA blocks per wave along the positions.  2 (default): 8 waves (4 x 2), each 64 x 64.  4 (experiment, VLG_CONV_NWM=4): 4 waves
+// NWM: 32-row MFMA blocks per wave along the positions.  2 (default): 8 waves (4 x 2), each 64 x 64.  1 (experiment, VLG_CONV_NWM=1): 16
+// waves (8 x 2), each 32 x 64 - four waves per SIMD.  4 (experiment, VLG_CONV_NWM=4): 4 waves
 // (2 x 2), each 128 x 64 - every B fragment feeds 4 MFMAs instead of 2, 25 % fewer LDS bytes per FLOP, measured slower (138 vs 106 ms).
 template <typename T, int HT_TT, int HT_TH, int NWM = 2, bool ASH = false>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
 __global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const
 
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
-  const int wrow = tid >> 2, wch = tid & 3;       // (+ 64 rows for the second chunk of a 256-thread workgroup)
+  // (+ 64 rows for the second chunk of a 256-thread workgroup; with 1024 threads the upper half repeats the lower half's loads and stores)
+  const int wrow = (tid & 511) >> 2, wch = tid & 3;
   const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
   const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
   const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
@@ -636,7 +638,8 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
         hipError_t e = hipSuccess;
         for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2>),
                               reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 4>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 4>),
-                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2, true>)})
+                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2, true>),
+                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 1>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 1>)})
           if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_LDS_BYTES);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
@@ -659,7 +662,9 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       } stop{(e0 && e1) ? e1 : nullptr, st};
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
         const long long tiles = (long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
-        if (nwm == 4)
+        if (nwm == 1)
+          conv_halo_kernel<T, 1, 8, 1><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 1024, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else if (nwm == 4)
           conv_halo_kernel<T, 1, 8, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
         else if (ash)
           conv_halo_kernel<T, 1, 8, 2, true><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
@@ -667,7 +672,9 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
           conv_halo_kernel<T, 1, 8, 2><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       } else {
         const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW);
-        if (nwm == 4)
+        if (nwm == 1)
+          conv_halo_kernel<T, 2, 4, 1><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 1024, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else if (nwm == 4)
           conv_halo_kernel<T, 2, 4, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
         else if (ash)
           conv_halo_kernel<T, 2, 4, 2, true><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
