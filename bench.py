@@ -199,9 +199,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=538.0,
                     help="an extra run starts only if the process would still be younger than this when it ends (the driver stops the default run at 600 s)")
     ap.add_argument("--hidden-tokens", type=int, default=256, help="tokens of the short DiffLoss-head run")
-    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="batch lanes inside generate (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of HIP-graph replay")
-    ap.add_argument("--attn-inlaunch", action="store_true", help="merge the split-KV partials inside the attention launch (slower)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -260,9 +258,7 @@ def main():
     N = a.new_tokens or vae_t * a.latent ** 2
     full = N == vae_t * a.latent ** 2
     gpt = build_gpt(V, a, device)
-    gpt.lanes = a.lanes
     gpt.use_graph = not a.no_graph
-    gpt.attn_inlaunch = a.attn_inlaunch
     vae = None
     if not a.no_vae and full:
         # CausalVAEModel constructor defaults with embed_dim = vae_embed_dim (the only decoder topology

@@ -136,17 +136,25 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
 /* options: "graph" (default 1) = HIP-graph replay of the decode step; "time_attn" (default 0) = eager decode loop
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
- * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "fuse_qkv" (0: RoPE + KV append inside attention),
- * "attn_inlaunch" (0: split-KV partials merged inside the attention launch), "splitk_inlaunch" (0), "dl_persist" (1: DiffLoss sampler
- * as one persistent launch per token), "kv_block" / "kv_pool_blocks" (sessions, see above), "gemm_lds" (0: decode GEMMs
- * with LDS-DMA operand staging and RMSNorm row statistics handed from the producing to the consuming kernel), "lanes" (0 = auto, 1 or 2:
- * batch lanes on forked graph branches).  Unknown keys return VLG_ERR_BAD_ARG.                                       */
+ * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "dl_persist" (1: DiffLoss sampler as one persistent launch per
+ * token), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
+ * of rounds 1-2 - batch lanes, fuse_qkv, attn_inlaunch, splitk_inlaunch, gemm_lds - were removed in round 3; DESIGN.md section 5
+ * keeps their measurements.)                                                                                         */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
 /* real-valued options.  "cfg_iter" (default 1.0; hidden / DiffLoss head only): the `cfg` argument of DiffLoss.sample
  * (autoregressive/models/diffloss.py:35-41 -> SimpleMLPAdaLN.forward_with_cfg :240-248, passed as cfg_iter by generate_video_diff.py:89-91):
  * != 1 treats rows [0, B/2) of the batch as the conditional and rows [B/2, B) as the unconditional half of every pair (b, b + B/2): one
  * x_T draw per pair, the network sees the conditional half's x_t twice, eps = u + cfg (c - u); B must be even.                        */
 int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value);
+/* Device-side faults.  The persistent kernels of this handle (the DiffLoss sampler, the persistent decode step) exchange data between
+ * workgroups inside one launch and bound every wait; a wait that runs out (the grid was not fully resident because something else held
+ * compute units, or option "debug_spin_max" forced it) records a fault word in host-visible memory and the kernel drains.  Results of
+ * that call are invalid (latents are NaN-poisoned).  vlg_gpt_status reports and clears the fault: VLG_OK, or VLG_ERR_STATE with the
+ * fault's kernel / phase in vlg_last_error().  sync != 0 first waits for the handle's stream (vlg_gpt_generate itself returns with the
+ * work enqueued); vlg_gpt_generate and the session calls also return VLG_ERR_STATE on entry while an uncollected fault is pending.
+ * Option "debug_spin_max" (default 0 = the built-in bound of ~1 s): spin bound of every in-launch wait; 1 makes the first wait that is
+ * not satisfied at once give up - how the tests inject a time-out without oversubscribing the chip.                              */
+int vlg_gpt_status(vlg_gpt_t* h, int32_t sync);
 /* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last
  * call and replays it while shape, sampling parameters, options and buffer addresses are unchanged                           */
 int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count);

@@ -294,23 +294,6 @@ def test_t2v_adapter2(golden, dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_unfused_qkv_path_matches_fused(golden, dt):
-    """RoPE + KV append can run inside the attention kernel (option fuse_qkv, off by default: the QKV GEMM's epilogue does it); the
-    two placements must give the same tokens."""
-    import video_llamagen_amd as V
-    cfg = cases.TINY_HD100 if dt == "fp32" else cases.TINY_C2I
-    m, _ = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16)
-    cond, _ = _inputs(cfg)
-    m.fuse_qkv = True
-    a, ta = V.generate(m, cond, 16, cfg_scale=2.5, sample_logits=False, return_trace=True)
-    m.fuse_qkv = False
-    b, tb = V.generate(m, cond, 16, cfg_scale=2.5, sample_logits=False, return_trace=True)
-    d = (ta - tb).abs().max().item()
-    assert torch.equal(a, b), (a, b)
-    assert d <= (1e-5 if dt == 'fp32' else 0.0), d      # same arithmetic; fp32 may differ by FMA contraction only
-
-
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("tag,cfg", [("c2i", cases.TINY_C2I), ("t2i", cases.TINY_T2I)])
 def test_unfused_gemm_path_matches_fused(golden, tag, cfg, dt):
     """decode uses the fused skinny GEMMs (RMSNorm prologue, residual / RoPE+scatter / SwiGLU epilogues) when the shape allows;
@@ -328,51 +311,6 @@ def test_unfused_gemm_path_matches_fused(golden, tag, cfg, dt):
     if dt == "fp32":
         assert torch.equal(a, b)
         assert (a.cpu().numpy() == golden("gpt")[f"{tag}_fp32_cfg_ids"]).all()
-
-
-@pytest.mark.parametrize("tag,cfg", [("c2i", cases.TINY_C2I), ("t2i", cases.TINY_T2I)])
-def test_lds_gemm_path_vs_reference_golden(golden, tag, cfg):
-    """The optional LDS-DMA decode GEMMs (gemm_lds = True) against the reference's ids / logits (fp32: greedy ids bit-exact)."""
-    import video_llamagen_amd as V
-    g = golden("gpt")
-    m, _ = product_gpt(cfg, torch.float32)
-    m.gemm_lds = True
-    cond, masks = _inputs(cfg)
-    N = cfg["block_size"]
-    ids, tr = V.generate(m, cond, N, masks, cfg_scale=2.5, cfg_interval=6, sample_logits=False, return_trace=True)
-    np.testing.assert_allclose(to_np(tr), g[f"{tag}_fp32_cfg_logits"], atol=3e-4, rtol=1e-4)
-    assert (ids.cpu().numpy() == g[f"{tag}_fp32_cfg_ids"]).all()
-
-
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_batch_lanes_do_not_change_results(golden, lanes):
-    """The batch is split into independent lanes (forked graph branches) purely for overlap: every lane count must
-    reproduce the reference's ids / the same latents."""
-    import video_llamagen_amd as V
-    g = golden("gpt")
-    cfg = cases.TINY_T2I
-    m, _ = product_gpt(cfg)
-    m.lanes = lanes
-    cond, masks = _inputs(cfg)
-    ids, tr = V.generate(m, cond, 16, masks, cfg_scale=2.5, cfg_interval=6, sample_logits=False, return_trace=True)
-    assert (ids.cpu().numpy() == g["t2i_fp32_cfg_ids"]).all()
-    np.testing.assert_allclose(to_np(tr), g["t2i_fp32_cfg_logits"], atol=3e-4, rtol=1e-4)
-    noise = torch.from_numpy(cases.exp_noise((16, 3, cfg["vocab_size"]), seed=7))
-    ids = V.generate(m, cond, 16, masks, cfg_scale=3.0, temperature=0.9, top_k=50, top_p=0.95, sample_logits=True, noise=noise)
-    _assert_sampled_ids(ids.cpu().numpy(), g["t2i_fp32_sample_ids"], g["t2i_fp32_sample_margin"], g["t2i_fp32_sample_slack"])
-    # Philox noise is keyed by the global sample id: identical draws for any lane split
-    m.lanes = 1
-    a = V.generate(m, cond, 16, masks, temperature=1.0, top_k=20, sample_logits=True, seed=5).cpu().numpy()
-    m.lanes = lanes
-    b = V.generate(m, cond, 16, masks, temperature=1.0, top_k=20, sample_logits=True, seed=5).cpu().numpy()
-    assert (a == b).mean() > 0.98
-    cfgv = cases.TINY_T2V
-    mv, _ = product_gpt(cfgv)
-    mv.lanes = lanes
-    c, mk = cases.text_cond(2, cfgv["cls_token_num"], cfgv["caption_dim"], lens=[8, 4])
-    lat = V.generate_t2v(mv, torch.from_numpy(c), 48, torch.from_numpy(mk))
-    ref = golden("t2v")["t2v_fp32_latents"]
-    assert np.abs(to_np(lat) - ref).max() < 3e-4 * max(1.0, np.abs(ref).max())
 
 
 def _diff_model(dtype, steps=10):
@@ -400,17 +338,17 @@ def test_diffloss_head_vs_reference_golden(golden):
     assert tuple(lat.shape) == ref.shape
     # fp32: 10 chained network evaluations per token, values O(10): 1e-3 relative to the output range
     assert np.abs(to_np(lat) - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
-    # batched semantics (each sample independent) vs the oracle, incl. eager path and lanes
+    # batched semantics (each sample independent) vs the oracle, incl. the eager path
     B = 3
     noise = cases.rng(55).standard_normal((N, S + 1, B, C), dtype=np.float32)
     c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5])
     om = O.GPTOracle(cfg, sd, "fp32")
     refb = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=1.0)
-    for graph, lanes in ((True, 1), (False, 1), (True, 2)):
-        m.use_graph, m.lanes = graph, lanes
+    for graph in (True, False):
+        m.use_graph = graph
         latb = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=1.0, noise=torch.from_numpy(noise))
-        assert np.abs(to_np(latb) - refb).max() < 1e-3 * max(1.0, np.abs(refb).max()), (graph, lanes)
-    m.use_graph, m.lanes = True, 0
+        assert np.abs(to_np(latb) - refb).max() < 1e-3 * max(1.0, np.abs(refb).max()), graph
+    m.use_graph = True
     # the unfused sampler (27 launches per reverse step) stays as the fallback for shapes the fused GEMM does not tile
     m.fuse_gemm = False
     latu = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=1.0, noise=torch.from_numpy(noise))
@@ -557,10 +495,58 @@ def test_diffloss_persistent_sampler_bf16_full_width():
     assert torch.isfinite(a32).all() and (a32 - c32).abs().max().item() < 1e-3 * max(1.0, c32.abs().max().item())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_diffloss_persistent_sampler_bench_instance_vs_oracle(dt):
+    """The benchmark's instance of the persistent sampler - W 1024, depth 3, 100 reverse steps, dl_persist_kernel<T, NKBW, FULL, 3> with
+    resident weight fragments - against the ORACLE (not only the launch chain): first token of 9 rows (two full 4-row groups + a ragged
+    one), bf16 against DiffLossOracle(dt="bf16") (same rounding points: 100 chained network evaluations in bf16, values O(1-10),
+    tolerance 8e-2 of the output range, as the full-size GPT tests), fp32 against the fp32 oracle at 1e-3."""
+    import video_llamagen_amd as V
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    m, cfg, sd = _diff_model_w(tdt, 1024, 100)
+    C, N, S, B = cfg["vae_embed_dim"], 1, 100, 9
+    noise = cases.rng(67).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4, 3, 6, 8])
+    om = O.GPTOracle(cfg, sd, dt)
+    ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S, dt=dt), c, N, mk, noise, temperature=1.0)
+    lat = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+    assert np.isfinite(lat).all()
+    tol = 8e-2 if dt == "bf16" else 1e-3
+    assert np.abs(lat - ref).max() < tol * max(1.0, np.abs(ref).max()), np.abs(lat - ref).max()
+    m.dl_persist = False                                  # and the launch chain at the same shape, same bar
+    chain = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+    assert np.abs(chain - ref).max() < tol * max(1.0, np.abs(ref).max())
+
+
+def test_persistent_kernel_timeout_is_an_error_not_nan():
+    """A wait inside a persistent kernel that runs out must surface as VLG_ERR_STATE (vlg_gpt_status / the mirror's generate), not as
+    NaN results under VLG_OK.  Injected cheaply: debug_spin_max = 1 makes the first in-launch wait that is not satisfied at once give
+    up (no oversubscribed grid, the kernel drains in microseconds).  The handle works again afterwards."""
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib
+    m, cfg, sd = _diff_model_w(torch.float32, 256, 10)
+    B, N = 6, 2
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4])
+    good = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    assert torch.isfinite(good).all()
+    m.debug_spin_max = 1
+    with pytest.raises(_lib.VlgError) as ei:
+        V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    assert ei.value.code == _lib.VLG_ERR_STATE and "ran out" in str(ei.value)
+    # asynchronous form: the C call returns VLG_OK with the work enqueued, the fault is collected by status() - once
+    m.check_faults = False
+    V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    with pytest.raises(_lib.VlgError):
+        m.status()
+    m.status()
+    m.debug_spin_max, m.check_faults = 0, True
+    again = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    assert torch.equal(again, good)
+
+
 def test_full_width_decode_paths_agree():
     """BASELINE config-4 widths (GPT-XL: D 1280, 20 heads, F 3584, bf16, 32 rows, 120 text tokens) on a 2-layer stack: the exact
-    kernel instances of the benchmark.  Size-independent properties: the fused-GEMM decode path, the slab path and the fused-QKV
-    attention path agree; two runs are bitwise identical; outputs are finite."""
+    kernel instances of the benchmark.  Size-independent properties: the fused-GEMM decode path and the slab path agree; two runs are bitwise identical; outputs are finite."""
     import video_llamagen_amd as V
     m = V.Transformer(V.ModelArgs(dim=1280, n_layer=2, n_head=20, block_size=1024, cls_token_num=120, model_type="t2v", vae_embed_dim=8,
                                   num_frames=17, t_downsample_size=4)).to("cuda", torch.bfloat16)
@@ -574,37 +560,15 @@ def test_full_width_decode_paths_agree():
     a = V.generate_t2v(m, cond, 40, mask)
     b = V.generate_t2v(m, cond, 40, mask)
     assert torch.equal(a, b) and torch.isfinite(a).all()
-    m.attn_inlaunch = True             # split-KV partials merged by the last-arriving workgroup: same arithmetic, same order
-    assert torch.equal(a, V.generate_t2v(m, cond, 40, mask))
-    m.attn_inlaunch = False
-    # residual GEMMs with the K range split over workgroups and merged in-launch (off by default: slower): same sums, other order
-    from video_llamagen_amd import _lib
-    _lib.check(_lib.lib().vlg_gpt_set_option(m._handle, b"splitk_inlaunch", C.c_int64(1)))
-    sk = V.generate_t2v(m, cond, 40, mask)
-    _lib.check(_lib.lib().vlg_gpt_set_option(m._handle, b"splitk_inlaunch", C.c_int64(0)))
-    assert torch.isfinite(sk).all() and torch.equal(sk[:, 0], a[:, 0]) and (sk[:, :3] - a[:, :3]).abs().max().item() < 2e-2 * a.abs().max().item()
-    # LDS-DMA form of the decode GEMMs (operands staged by global_load_lds, row statistics handed from kernel to kernel): same
-    # rounding points, other fp32 summation order
-    m.gemm_lds = True
-    lds = V.generate_t2v(m, cond, 40, mask)
-    assert torch.isfinite(lds).all() and torch.equal(lds, V.generate_t2v(m, cond, 40, mask))
-    assert (lds[:, :3] - a[:, :3]).abs().max().item() < 2e-2 * a.abs().max().item()
-    lds64 = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)          # 64 rows: two 32-row workgroups per n-tile
-    m.gemm_lds = False
-    ref64 = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
-    assert (lds64[:, :3] - ref64[:, :3]).abs().max().item() < 3e-2 * max(a.abs().max().item(), ref64.abs().max().item())
     m.fuse_gemm = False
     c = V.generate_t2v(m, cond, 40, mask)
-    m.fuse_qkv = True
-    d = V.generate_t2v(m, cond, 40, mask)
     scale = a.abs().max().item()
     # The latent feeds back as the next input and the weights are random, so one-ulp bf16 differences (fp32 summation order before
     # each rounding) grow geometrically with the token index: only the first tokens are comparable across GEMM paths.
     assert torch.equal(a[:, 0], c[:, 0])
     assert (a[:, :3] - c[:, :3]).abs().max().item() < 2e-2 * scale
-    assert torch.equal(c[:, 0], d[:, 0]) and (c[:, :3] - d[:, :3]).abs().max().item() < 2e-2 * scale
     # CFG doubles the rows to 64 (MT = 4 kernels, 8-wave prologue variants)
-    m.fuse_gemm, m.fuse_qkv = True, False
+    m.fuse_gemm = True
     e = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
     m.fuse_gemm = False
     f = V.generate_t2v(m, cond, 8, mask, cfg_scale=2.0)
@@ -693,6 +657,7 @@ def test_generate_is_stream_ordered_and_reuses_its_graph():
     kw = dict(cfg_scale=4.0, temperature=1.0, top_k=2000, top_p=1.0, seed=3)
     ref = V.generate(m, c, 256, **kw)
     torch.cuda.synchronize()
+    m.check_faults = False                # the Python mirror's default waits for the call to raise on device faults; the C call does not
     n0 = m.graphs_built()
     assert n0 >= 1
     side = torch.cuda.Stream()

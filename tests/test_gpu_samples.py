@@ -246,6 +246,14 @@ def test_block_granular_kv_sessions_vs_reference_golden(golden):
     assert e.deferred == 0
     for i in range(3):
         assert len(out[i]) == lens[i] and (out[i] == g["c2i_fp32_greedy_ids"][i][:lens[i]]).all(), i
+    # a deferral at slot 0 while slot 1 is mid-request: two slots, 1 + 4 blocks; the 3-token request (1 block) finishes first, the
+    # queued full-length one (3 blocks) then has to wait for slot 1's request - which must keep running undisturbed meanwhile
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=2, max_tokens=N, kv_block_size=8, num_kv_blocks=5)
+    lens = (3, N, N)
+    out = run(e, False, lens)
+    assert e.deferred > 0
+    for i in range(3):
+        assert len(out[i]) == lens[i] and (out[i] == g["c2i_fp32_greedy_ids"][i][:lens[i]]).all(), i
 
     # text-conditioned: 120 condition positions + 16 tokens = 9 blocks of 16 per row (18 per request under guidance)
     cfg = cases.TINY_T2I

@@ -255,14 +255,14 @@ constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) *
 
 // T = bf16: 32-channel chunks, v_mfma_f32_32x32x16_bf16.  T = float (the reference runs the VQ-16 decoder in fp32): 16-channel
 // chunks - the same 64-byte patch rows and LDS image - on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak instead of a direct conv).
-// NWM: 32-row MFMA blocks per wave along the positions.  2 (default): 8 waves (4 x 2), each 64 x 64.  1 (experiment, VLG_CONV_NWM=1): 16
-// waves (8 x 2), each 32 x 64 - four waves per SIMD.  4 (experiment, VLG_CONV_NWM=4): 4 waves
-// (2 x 2), each 128 x 64 - every B fragment feeds 4 MFMAs instead of 2, 25 % fewer LDS bytes per FLOP, measured slower (138 vs 106 ms).
-template <typename T, int HT_TT, int HT_TH, int NWM = 2, bool ASH = false>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
-__global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+// NWM: 32-row MFMA blocks per wave along the positions: 8 waves (4 x 2), each 64 x 64.  (Round 2 measured 16 waves of 32 x 64, 4 waves of
+// 128 x 64 and taps 1 / 2 as DPP lane shifts of tap 0's fragment: all slower; removed in round 3.)
+template <typename T, int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
+__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
                                                                const float* __restrict__ bias, const T* __restrict__ residual,
                                                                T* __restrict__ out_cl, float* __restrict__ out_planar) {
-  constexpr int NTHR = 1024 / NWM;           // 512 / 256 threads
+  constexpr int NWM = 2;
+  constexpr int NTHR = 1024 / NWM;           // 512 threads
   constexpr int HT_SLOTS = ht_slots<NTHR>();
   constexpr int WPT = 512 / NTHR;            // weight chunks per thread per tap: 128 rows x 4 chunks over the workgroup
   constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -390,42 +390,7 @@ __global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  // ASH: the three taps of a kernel row read the same patch rows shifted by one position, and a lane's row is its neighbour's row + 1 -
-  // so only tap 0's fragment is read from LDS, taps 1 and 2 are lane shifts of it (DPP wave_shl:1: lane i takes lane i + 1's registers;
-  // lanes 31 and 63, whose neighbour belongs to the other channel half, read their two extra rows themselves).  A-fragment LDS traffic / 3
-  // same values, same MFMA order.  An experiment (VLG_CONV_ASHIFT=1): measured slower than three plain reads, 120 vs 106 ms per decode call
-  //  - LDS bytes are not what bounds this kernel.
-  typedef unsigned int ash_u4 __attribute__((ext_vector_type(4)));   // a native vector: selects stay in registers (HIP's uint4 struct went through scratch)
-  auto shl1 = [&](const ash_u4& v) __attribute__((always_inline)) {
-    ash_u4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[e], 0x130, 0xf, 0xf, false);
-    return o;
-  };
   auto compute = [&](const uint4* hbuf, const uint4* wbuf, int toff) __attribute__((always_inline)) {   // toff: patch row offset of tap (a, i, 0)
-    ash_u4 ash0[2][NWM], ash1[2][NWM], ash2[2][NWM];   // taps 0, 1, 2: [channel half][m block]
-    if constexpr (ASH) {
-      const ash_u4* hb4 = reinterpret_cast<const ash_u4*>(hbuf);
-      const bool edge = r32 == 31;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int mi = 0; mi < NWM; ++mi) {
-          const int row = hb[mi] + toff;
-          const ash_u4 t0 = hb4[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
-          ash_u4 f1 = t0, f2 = t0;
-          if (edge) {   // two lanes of the wave: an exec-masked read moves 32 bytes, not 1 KB
-            f1 = hb4[(row + 1) * 4 + ((2 * kk + hh) ^ (((row + 1) >> 2) & 3))];
-            f2 = hb4[(row + 2) * 4 + ((2 * kk + hh) ^ (((row + 2) >> 2) & 3))];
-          }
-          const ash_u4 s1 = shl1(t0);
-          const ash_u4 t1 = edge ? f1 : s1;
-          const ash_u4 s2 = shl1(t1);
-          ash0[kk][mi] = t0;
-          ash1[kk][mi] = t1;
-          ash2[kk][mi] = edge ? f2 : s2;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
@@ -433,13 +398,8 @@ __global__ __launch_bounds__(1024 / NWM) void conv_halo_kernel(ConvDesc d, const
         uint4 af[NWM], bfr[2];
 #pragma unroll
         for (int mi = 0; mi < NWM; ++mi) {
-          if constexpr (ASH) {
-            const ash_u4 t = j == 0 ? ash0[kk][mi] : (j == 1 ? ash1[kk][mi] : ash2[kk][mi]);
-            af[mi] = make_uint4(t[0], t[1], t[2], t[3]);
-          } else {
-            const int row = hb[mi] + toff + j;
-            af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
-          }
+          const int row = hb[mi] + toff + j;
+          af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -631,15 +591,10 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
   {
     static const bool halo_off = getenv("VLG_CONV_HALO") != nullptr && atoi(getenv("VLG_CONV_HALO")) == 0;   // A/B knob
     if (!halo_off && conv_halo_ok(d, sizeof(T) == 2 ? 32 : 16)) {
-      static const int nwm = getenv("VLG_CONV_NWM") ? atoi(getenv("VLG_CONV_NWM")) : 2;   // A/B knob: 4 = four waves of 128 x 64
-      static const int ash = getenv("VLG_CONV_ASHIFT") ? atoi(getenv("VLG_CONV_ASHIFT")) : 0;   // A/B knob: taps 1, 2 as lane shifts of tap 0
       static bool attr_set = false;   // per instantiation of conv_forward<T>
       if (!attr_set) {
         hipError_t e = hipSuccess;
-        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2>),
-                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 4>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 4>),
-                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 2, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 2, true>),
-                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, 1>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, 1>)})
+        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8>)})
           if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_LDS_BYTES);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
@@ -662,24 +617,10 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       } stop{(e0 && e1) ? e1 : nullptr, st};
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
         const long long tiles = (long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
-        if (nwm == 1)
-          conv_halo_kernel<T, 1, 8, 1><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 1024, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else if (nwm == 4)
-          conv_halo_kernel<T, 1, 8, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else if (ash)
-          conv_halo_kernel<T, 1, 8, 2, true><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else
-          conv_halo_kernel<T, 1, 8, 2><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        conv_halo_kernel<T, 1, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       } else {
         const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW);
-        if (nwm == 1)
-          conv_halo_kernel<T, 2, 4, 1><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 1024, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else if (nwm == 4)
-          conv_halo_kernel<T, 2, 4, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 256, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else if (ash)
-          conv_halo_kernel<T, 2, 4, 2, true><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
-        else
-          conv_halo_kernel<T, 2, 4, 2><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        conv_halo_kernel<T, 2, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       }
       return VLG_OK;
     }

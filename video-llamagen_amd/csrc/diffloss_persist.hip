@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
           any = any || need[u];
         }
         if (!any) break;
-        if (spin >= (1 << 20)) {
+        if (spin >= p.spin_max) {
           ok_sm = 0;
           break;
         }
@@ -679,6 +679,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 #ifdef VLG_DP_PROF
   if (p.prof && blockIdx.x == 0 && tid < 16) p.prof[tid] = prof_s[tid];
 #endif
+  // an exchange wait ran out: tell the host (vlg_gpt_status); system scope - the word lives in pinned host memory
+  if (!alive && tid == 0 && p.fault) __hip_atomic_store(p.fault, kFaultDlPersist | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // ---- results: the workgroup of column tile 0 writes its group's rows (NaN when an exchange timed out) -------------------------
   if (tile == 0 && tid < DP_R * 16) {
     const int row = tid / 16, c = tid % 16;
@@ -699,13 +701,14 @@ size_t dl_persist_xbuf_bytes(int B, int W, int esz) { return (size_t)2 * cdiv(B,
 namespace {
 // compute units of the current device: every workgroup of the launch must be resident at once (they wait for each other), and each takes a
 // whole CU (LDS >= 96 KB)
-int dp_cu_count() {
-  static int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return cus;
-  }();
-  return n;
+int dp_cu_count() {   // per device: a process may drive several
+  static int cache[64] = {};
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && cache[dev] > 0) return cache[dev];
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev < 64) cache[dev] = cus;
+  return cus;
 }
 }  // namespace
 
@@ -722,10 +725,12 @@ template bool dl_persist_ok<bf16>(int, int, int, int);
 namespace {
 template <typename T, int NKBW, bool FULL, int DEPTH>
 int dp_launch1(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};   // the attribute is per device (a code object is loaded per device)
+  int dev = 0;
+  VLG_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr[dev]) {
     VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dl_persist_kernel<T, NKBW, FULL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    attr = true;
+    if (dev >= 0 && dev < 64) attr[dev] = true;
   }
   dl_persist_kernel<T, NKBW, FULL, DEPTH><<<grid, 256, lds, st>>>(p);
   return VLG_OK;

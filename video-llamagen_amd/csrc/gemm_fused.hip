@@ -146,11 +146,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   }
   const int n0 = bx * NC, m0 = by * (MT * 16);
   const int nkb = K / KBLK;
-  const int split = blockIdx.z, splits = gridDim.z;   // > 1 only for !PRO kernels (host-enforced)
   VLG_KT(0);
 
   __shared__ float red[NW][NH][MT][256];
-  __shared__ int ticket_sm;
   __shared__ float ssq_sm[NW][MT * 16];
   __shared__ u32x4_t gsm[PRO ? 256 : 1];   // norm weight, K * sizeof(T) <= 4 KiB
 
@@ -213,8 +211,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   u32x4_t a[NB][MT][4], b[NB][NH][4];
   u32x4_t gld = u32x4_t{0u, 0u, 0u, 0u};
   bool first = true;
-  const int kstride = NW * splits;
-  for (int kb0 = split * NW + wave; kb0 < nkb; kb0 += NB * kstride) {
+  const int kstride = NW;
+  for (int kb0 = wave; kb0 < nkb; kb0 += NB * kstride) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int kb = kb0 + i * kstride;
@@ -329,56 +327,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   const int t = threadIdx.x;
   const int e = t >> 6, l2 = t & 63;
   const int col = n0 + (l2 & (NC - 1));
-  float part[MT];
-  if constexpr (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE)) {
-    if (splits > 1) {
-      // In-launch split-K combine (cdna_hip_programming.md §5 "In-launch split-K reduction", write-through form): every K-slice
-      // workgroup writes its fp32 tile with sc1 (agent-scope) stores, drains them and takes a ticket; the last arriver reads the
-      // slices back with sc1 loads in slice order (deterministic) and runs the epilogue.  No release / acquire fence: an
-      // agent-scope acquire invalidates the XCD's whole L2.  The counter is reset by the last arriver (zero at allocation).
-      const int tile = by * gridDim.x + bx;
-      float* slab = fa.slabs + ((size_t)tile * splits + split) * (MT * 256);
-      if (t < 256) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float v = 0.f;
-#pragma unroll
-          for (int wv = 0; wv < NW; ++wv) v += red[wv][0][mt][t];
-          __hip_atomic_store(slab + mt * 256 + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t == 0) ticket_sm = __hip_atomic_fetch_add(fa.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (ticket_sm != splits - 1) return;
-      if (t == 0) __hip_atomic_store(fa.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t < 256) {
-        const float* base = fa.slabs + (size_t)tile * splits * (MT * 256);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float v = 0.f;
-          for (int sp2 = 0; sp2 < splits; ++sp2)
-            v += __hip_atomic_load(base + (size_t)sp2 * (MT * 256) + mt * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          part[mt] = v;
-        }
-      }
-    }
-  }
   if (t >= 256) return;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
     float s0 = 0.f, s1 = 0.f, sp = 0.f;
-    if (!PRO && (EPI == EPI_RESID || EPI == EPI_STORE) && splits > 1) {
-      s0 = part[mt];
-    } else {
 #pragma unroll
-      for (int wv = 0; wv < NW; ++wv) {
-        s0 += red[wv][0][mt][t];
-        if constexpr (NH == 2) s1 += red[wv][1][mt][t];
-        if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
-      }
+    for (int wv = 0; wv < NW; ++wv) {
+      s0 += red[wv][0][mt][t];
+      if constexpr (NH == 2) s1 += red[wv][1][mt][t];
+      if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
     }
     if (row >= M) continue;
     if (NC == 8 && (l2 & 8)) continue;   // mirror lanes
@@ -423,325 +381,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       else
         dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + kv_row_index(fa.pages, bq, hh, fa.H, fa.S, p) * fa.hd + d;
       DT<T>::st(dst, o);
-    }
-  }
-  VLG_KT(3);
-}
-
-// =====================================================================================================================
-// LDS-DMA form of the same GEMM (round 2).  Measured on MI355X (tools/microbench/load_lab.hip, 36 cold weight sets in a graph
-// chain, M = 32): pulling a workgroup's 40 KB weight tile + 80 KB activation rows as fragment-shaped loads into registers takes
-// 6.2 us per launch, as whole-line LDS-DMA (global_load_lds_dwordx4) from 8 waves 4.2 us; and with the operands in LDS the
-// kernel no longer holds 190 VGPRs of fragments between the loads and the first MFMA.
-//
-//   * every operand byte enters through LDS-DMA in 1 KB pieces = 4 rows x 256 B (one K block of 4 rows): full 128-B lines from
-//     HBM / L2, no VGPR staging.  The LDS image of a piece is [4 rows][16 chunks of 16 B] with chunk c of row r stored at slot
-//     c ^ (r & 15) (the permutation is applied to the per-lane SOURCE address; LDS-DMA writes lane-linear), so the 16 rows of a
-//     ds_read_b128 lane group fall on 16 different 16-byte slots: fragment reads are conflict-free.
-//   * K is walked in stages of `kps` K blocks through a ring of `nslot` stage slots; everything that fits is in flight from the
-//     first instruction (qkv / wo: the whole K range), later stages are issued as slots drain (w13, w2).  Waits are counted
-//     (s_waitcnt vmcnt(n) leaves the younger stages in flight) and followed by a raw s_barrier.
-//   * wave j of a stage's K blocks: K block j, j + NW, ...; per-wave accumulators are summed through LDS at the end (as before).
-//   * PRO_NORM does not need its rows resident: the kernel that wrote the residual stream left per-tile sums of squares
-//     (FusedGemm::sq_out -> sq_in); without them the workgroup sums x^2 itself from global memory first.
-// Epilogues are those of gemm_fused_kernel.
-// =====================================================================================================================
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-  n = __builtin_amdgcn_readfirstlane(n);
-#define VLG_W(i) \
-  case i:        \
-    asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); \
-    break;
-  switch (n) {
-    VLG_W(0) VLG_W(1) VLG_W(2) VLG_W(3) VLG_W(4) VLG_W(5) VLG_W(6) VLG_W(7) VLG_W(8) VLG_W(9) VLG_W(10) VLG_W(11) VLG_W(12) VLG_W(13)
-    VLG_W(14) VLG_W(15) VLG_W(16) VLG_W(17) VLG_W(18) VLG_W(19) VLG_W(20) VLG_W(21) VLG_W(22) VLG_W(23) VLG_W(24) VLG_W(25) VLG_W(26)
-    VLG_W(27) VLG_W(28) VLG_W(29) VLG_W(30) VLG_W(31) VLG_W(32) VLG_W(33) VLG_W(34) VLG_W(35) VLG_W(36) VLG_W(37) VLG_W(38) VLG_W(39)
-    VLG_W(40)
-    default:
-      if (n > 40)
-        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");   // stricter than asked: always safe
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-#undef VLG_W
-}
-
-constexpr int kLdsScratch = 8192;   // rs[64] | stat partials [16][64] | norm weight (<= 4 KB)
-
-template <typename T, int MT, int NH, int NW, bool PRO, int EPI>
-__global__ __launch_bounds__(64 * NW) void gemm_lds_kernel(const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, FusedGemm fa,
-                                                          int kps, int nslot) {
-  constexpr int KBLK = KB<T>::KBLK;       // elements per 256-byte K block
-  constexpr int EPV = 16 / sizeof(T);
-  constexpr int PX = MT * 4, PW = NH * 4, PP = PX + PW;   // 1 KB pieces per K block: activations, weights
-  constexpr int KB_BYTES = PP * 1024;
-  constexpr int ROWS = MT * 16;
-  constexpr int NT = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (gridDim.y == 2 && (gridDim.x & 7) == 0) {   // row halves of one n-tile on one XCD (see gemm_fused_kernel)
-    const int id = blockIdx.y * gridDim.x + blockIdx.x;
-    bx = (id & 7) + 8 * (id >> 4);
-    by = (id >> 3) & 1;
-  }
-  const int n0 = bx * 16, m0 = by * ROWS;
-  const int nkb = K / KBLK;
-  const int nst = (nkb + kps - 1) / kps;
-  char* scratch = lds + (size_t)nslot * kps * KB_BYTES;
-  float* rs_sm = reinterpret_cast<float*>(scratch);                  // [64]
-  float* part_sm = rs_sm + 64;                                       // [NT / ROWS][ROWS]
-  u32x4_t* gsm = reinterpret_cast<u32x4_t*>(scratch + 4096);         // norm weight
-  VLG_KT(0);
-
-  // ---- 1. plain loads first (oldest in the vmcnt queue): epilogue operands, norm weight, row statistics --------------------
-  const int et = threadIdx.x, ee = et >> 6, el = et & 63;
-  const int ecol = n0 + (el & 15);
-  float eres[MT], ecx[MT], ecy[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
-  int epos = 0;
-  const int32_t* erow_pos = nullptr;
-  if constexpr (EPI == EPI_QKV) {
-    epos = fa.state->pos;
-    erow_pos = fa.row_pos;
-  }
-#ifdef VLG_ABL_NOEPIPRE
-  if (et < 0) {
-#else
-  if (et < 256) {
-#endif
-    if constexpr (EPI == EPI_RESID || EPI == EPI_GATED) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
-        row = row < M ? row : M - 1;
-        eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + (size_t)row * N + ecol);
-        if constexpr (EPI == EPI_GATED) ecx[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.gate) + (size_t)row * fa.gate_stride + ecol);
-      }
-    }
-    if constexpr (EPI == EPI_QKV) {
-      const int D = fa.H * fa.hd;
-      const int d = (ecol % D) % fa.hd;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
-        row = row < M ? row : M - 1;
-        const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
-        ecx[mt] = cp[0];
-        ecy[mt] = cp[1];
-      }
-    }
-  }
-  float psum = 0.f;
-  u32x4_t gld = u32x4_t{0u, 0u, 0u, 0u};
-  if constexpr (PRO) {
-    if ((int)threadIdx.x < K / EPV) gld = reinterpret_cast<const u32x4_t*>(fa.norm_w)[threadIdx.x];
-    constexpr int NPART = NT / ROWS;
-    const int srow = threadIdx.x % ROWS, sp = threadIdx.x / ROWS;
-    int grow = m0 + srow;
-    grow = grow < M ? grow : M - 1;
-#ifdef VLG_ABL_NOSTATS
-    if (fa.sq_in) {
-      psum = 1.0f;
-    } else {
-#else
-    if (fa.sq_in) {
-      for (int t = sp; t < fa.sq_tiles; t += NPART) psum += fa.sq_in[(size_t)t * fa.sq_stride + grow];
-    } else {
-#endif   // no producer statistics (first layer of a step): sum x^2 from global memory, 16 bytes per load
-      const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + (size_t)grow * K);
-      for (int c = sp; c < K / EPV; c += NPART) psum += sumsq<T>(xr[c]);
-    }
-  }
-
-  // ---- 2. LDS-DMA of the stages that fit ------------------------------------------------------------------------------------
-  const int lr = lane >> 4, lc = lane & 15;   // row within a piece, 16-byte slot within the row
-  int issued = 0;
-  auto pieces_of = [&](int s) {
-    const int kb0 = s * kps;
-    const int nk = (nkb - kb0) < kps ? (nkb - kb0) : kps;
-    return nk * PP;
-  };
-  auto my_count = [&](int s) {
-    const int np = pieces_of(s);
-    return np > wave ? (np - wave + NW - 1) / NW : 0;
-  };
-  auto issue_stage = [&](int s) {
-    const int kb0 = s * kps;
-    const int np = pieces_of(s);
-    char* slot = lds + (size_t)(s % nslot) * kps * KB_BYTES;
-    for (int p = wave; p < np; p += NW) {
-      const int kbi = p / PP, g = p - kbi * PP;
-      const size_t koff = (size_t)(kb0 + kbi) * KBLK;
-      __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(slot + (size_t)kbi * KB_BYTES + (size_t)g * 1024);
-      if (g < PX) {
-        const int rr = g * 4 + lr;                 // row of the workgroup's row block
-        int row = m0 + rr;
-        row = row < M ? row : M - 1;
-        const T* src = x + (size_t)row * K + koff + (size_t)((lc ^ (rr & 15)) * EPV);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4_t*>(src), dst, 16, 0, 0);
-      } else {
-        const int gw = g - PX, hf = gw >> 2;
-        const int rr = (gw & 3) * 4 + lr;          // weight row (= output column) of the 16-column tile
-        const T* src = w + (size_t)(n0 + rr + (NH == 2 ? hf * N : 0)) * K + koff + (size_t)((lc ^ rr) * EPV);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4_t*>(src), dst, 16, 0, 2);   // weights: read once, non-temporal
-      }
-    }
-    issued += my_count(s);
-  };
-  const int first = nst < nslot ? nst : nslot;
-  for (int s = 0; s < first; ++s) issue_stage(s);
-
-  // ---- 3. row scales (PRO) while the DMA is in flight --------------------------------------------------------------------------
-  if constexpr (PRO) {
-    constexpr int NPART = NT / ROWS;
-    const int srow = threadIdx.x % ROWS, sp = threadIdx.x / ROWS;
-    part_sm[sp * ROWS + srow] = psum;
-    if ((int)threadIdx.x < K / EPV) gsm[threadIdx.x] = gld;
-    __syncthreads();
-    if ((int)threadIdx.x < ROWS) {
-      float tot = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPART; ++i) tot += part_sm[i * ROWS + threadIdx.x];
-      rs_sm[threadIdx.x] = 1.0f / sqrtf(tot / (float)K + fa.eps);
-    }
-    // visible to everyone after the first stage barrier below
-  }
-
-  // ---- 4. stages.  Work unit = (m-tile, 64-byte sub-block s2 of a K block): wave (group, unit) handles its unit of every K block
-  // j = group (mod G) of a stage, so the RMSNorm arithmetic (the only real VALU work here) is spread evenly over all waves and each
-  // stage can be consumed as soon as it lands ------------------------------------------------------------------------------------------
-  constexpr int UNITS = MT * 4;
-  constexpr int G = NW / UNITS;
-  static_assert(NW % UNITS == 0, "waves must be a multiple of the units of a K block");
-  const int unit = wave % UNITS, grp = wave / UNITS;
-  const int mt_w = unit >> 2, s2_w = unit & 3;
-  const int frag_off = ((s2_w * 4 + q) ^ r) * 16;
-  f32x4_t acc[NH];
-#pragma unroll
-  for (int hf = 0; hf < NH; ++hf) acc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  int done = 0;   // this wave's pieces of stages 0..s
-  float rs_w = 1.f;
-  for (int s = 0; s < nst; ++s) {
-    done += my_count(s);
-    wait_vmcnt_le(issued - done);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if constexpr (PRO) {
-      if (s == 0) rs_w = rs_sm[mt_w * 16 + r];
-    }
-    const int kb0 = s * kps;
-    const int nk = (nkb - kb0) < kps ? (nkb - kb0) : kps;
-    const char* slot = lds + (size_t)(s % nslot) * kps * KB_BYTES;
-    for (int j = grp; j < nk; j += G) {
-      const char* kbase = slot + (size_t)j * KB_BYTES + (size_t)(r >> 2) * 1024 + (size_t)(r & 3) * 256 + frag_off;
-      u32x4_t a = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)mt_w * 4096);
-      u32x4_t b[NH];
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf) b[hf] = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)(PX + hf * 4) * 1024);
-#ifndef VLG_ABL_NONORM
-      if constexpr (PRO) norm_frag<T>(a, rs_w, gsm[(kb0 + j) * (KBLK / EPV) + s2_w * 4 + q]);
-#endif
-#pragma unroll
-      for (int hf = 0; hf < NH; ++hf) mfma_one<T>(a, b[hf], acc[hf]);
-    }
-    if (s + nslot < nst) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();     // every wave has its fragments of this slot in registers
-      asm volatile("" ::: "memory");
-      issue_stage(s + nslot);
-    }
-  }
-  VLG_KT(1);
-
-  // ---- 5. cross-wave reduction (aliases the stage slots) + epilogue ----------------------------------------------------------------------
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(lds);   // [NW][NH][256]: wave w holds a partial sum of m-tile (w % UNITS) / 4
-#pragma unroll
-  for (int hf = 0; hf < NH; ++hf)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[(wave * NH + hf) * 256 + e * 64 + lane] = acc[hf][e];
-  __syncthreads();
-  VLG_KT(2);
-  const int t = threadIdx.x;
-  if (t >= 256) return;
-  const int e = t >> 6, l2 = t & 63;
-  const int col = n0 + (l2 & 15);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
-    float s0 = 0.f, s1 = 0.f, sp = 0.f;
-#pragma unroll
-    for (int gg = 0; gg < G; ++gg)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const int wv = gg * UNITS + mt * 4 + s2;
-        s0 += red[(wv * NH + 0) * 256 + t];
-        if constexpr (NH == 2) s1 += red[(wv * NH + 1) * 256 + t];
-        if constexpr (EPI == EPI_QKV) sp += red[(wv * NH + 0) * 256 + (t ^ 1)];
-      }
-    float stored = 0.f;
-    const bool live = row < M;
-    if constexpr (EPI == EPI_RESID) {
-      stored = DT<T>::rt(eres[mt] + DT<T>::rt(s0));
-      if (live) DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, stored);
-    } else if constexpr (EPI == EPI_GATED) {
-      float v = s0;
-      if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
-      stored = DT<T>::rt(eres[mt] + DT<T>::rt(ecx[mt] * DT<T>::rt(v)));
-      if (live) DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, stored);
-    } else if constexpr (EPI == EPI_SWIGLU) {
-      const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
-      if (live) DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, DT<T>::rt(silu_g(av)) * bv);
-    } else if constexpr (EPI == EPI_STORE) {
-      float v = s0;
-      if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
-      v = DT<T>::rt(v);
-      if (fa.act == ACT_GELU_TANH) v = DT<T>::rt(gelu_g(v));
-      if (fa.act == ACT_SILU) v = DT<T>::rt(silu_g(v));
-      stored = v;
-      if (live) {
-        if (fa.out) DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, v);
-        if (fa.out_f32) fa.out_f32[(size_t)row * N + col] = v;
-      }
-    } else {  // EPI_QKV
-      if (live) {
-        const int D = fa.H * fa.hd;
-        const int sec = col / D, within = col - sec * D;
-        const int hh = within / fa.hd, d = within - hh * fa.hd;
-        const int bq = row / fa.Tq, tq = row - bq * fa.Tq;
-        const int p = (erow_pos ? erow_pos[bq] : epos) + tq;
-        const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
-        float o = xs;
-        if (sec < 2) {
-          float cx = ecx[mt], cy = ecy[mt];
-          if (erow_pos) {
-            const float* cp = fa.freqs + ((size_t)p * (fa.hd / 2) + d / 2) * 2;
-            cx = cp[0];
-            cy = cp[1];
-          }
-          o = (d & 1) ? __fadd_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy)) : __fsub_rn(__fmul_rn(xs, cx), __fmul_rn(xp, cy));
-        }
-        T* dst;
-        if (sec == 0)
-          dst = reinterpret_cast<T*>(fa.qbuf) + ((size_t)row * fa.H + hh) * fa.hd + d;
-        else
-          dst = reinterpret_cast<T*>(sec == 1 ? fa.kc : fa.vc) + kv_row_index(fa.pages, bq, hh, fa.H, fa.S, p) * fa.hd + d;
-        DT<T>::st(dst, o);
-      }
-    }
-    if constexpr (EPI == EPI_RESID || EPI == EPI_STORE || EPI == EPI_GATED) {
-      if (fa.sq_out) {   // sum of squares of this tile's 16 columns per row, for the RMSNorm prologue that reads these rows next
-        float sq = stored * stored;
-        sq += __shfl_xor(sq, 1);
-        sq += __shfl_xor(sq, 2);
-        sq += __shfl_xor(sq, 4);
-        sq += __shfl_xor(sq, 8);
-        if ((l2 & 15) == 0 && live) fa.sq_out[(size_t)bx * fa.sq_stride + row] = sq;
-      }
     }
   }
   VLG_KT(3);
@@ -921,78 +560,12 @@ void launch_epi(int epi, dim3 grid, hipStream_t st, const T* x, const T* w, int 
   }
 }
 
-template <typename T, int MT, int NW, bool PRO>
-int launch_lds(int epi, dim3 grid, size_t ldsb, hipStream_t st, const T* x, const T* w, int M, int N, int K, const FusedGemm& fa, int kps, int nslot) {
-#define VLG_LL(NH_, EPI_)                                                                                                                  \
-  do {                                                                                                                                     \
-    auto kern = gemm_lds_kernel<T, MT, NH_, NW, PRO, EPI_>;                                                                                \
-    static bool attr = false;                                                                                                              \
-    if (!attr) {                                                                                                                           \
-      VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
-      attr = true;                                                                                                                         \
-    }                                                                                                                                      \
-    kern<<<grid, 64 * NW, ldsb, st>>>(x, w, M, N, K, fa, kps, nslot);                                                                      \
-  } while (0)
-  switch (epi) {
-    case EPI_RESID: VLG_LL(1, EPI_RESID); break;
-    case EPI_QKV: VLG_LL(1, EPI_QKV); break;
-    case EPI_SWIGLU: VLG_LL(2, EPI_SWIGLU); break;
-    case EPI_GATED: VLG_LL(1, EPI_GATED); break;
-    default: VLG_LL(1, EPI_STORE); break;
-  }
-#undef VLG_LL
-  return VLG_OK;
-}
-
 int lds_knob(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
 
 }  // namespace
-
-// LDS-DMA kernel coverage: 256-byte K blocks, 16-column tiles; PRO needs the norm weight (K elements) in its 4 KB of scratch
-template <typename T>
-bool gemm_lds_ok(int M, int N, int K, bool pro, int epi) {
-  constexpr int KBLK = KB<T>::KBLK;
-  if (M < 1 || K % KBLK != 0 || N % 16 != 0) return false;
-  if (pro && (size_t)K * sizeof(T) > 4096) return false;
-  return true;
-}
-template bool gemm_lds_ok<float>(int, int, int, bool, int);
-template bool gemm_lds_ok<bf16>(int, int, int, bool, int);
-
-template <typename T>
-static int gemm_lds(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st) {
-  constexpr int KBLK = KB<T>::KBLK;
-  const int nh = epi == EPI_SWIGLU ? 2 : 1;
-  int mt = M > 16 ? 2 : 1;
-  // few n-tiles (N = D: wo, w2): 16-row workgroups so that twice the CUs stream (row halves of a tile share an XCD)
-  const bool rows16 = !pro && (epi == EPI_RESID || epi == EPI_GATED || epi == EPI_STORE) && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0;
-  if (rows16) mt = 1;
-  const int nkb = K / KBLK;
-  const int kb_bytes = (mt * 4 + nh * 4) * 1024;
-  const int budget = 160 * 1024 - kLdsScratch;
-  const int fit = budget / kb_bytes;                 // K blocks that can be resident
-  // small stages so that a stage is consumed (normalised, multiplied) while the later ones are still landing; as many slots as fit
-  static const int kps_knob = lds_knob("VLG_GEMM_KPS", 2);
-  int kps = kps_knob < 1 ? 1 : kps_knob;
-  if (kps > nkb) kps = nkb;
-  if (kps > fit) kps = fit;
-  const int nst = cdiv(nkb, kps);
-  int nslot = fit / kps;
-  if (nslot > nst) nslot = nst;
-  size_t ldsb = (size_t)nslot * kps * kb_bytes + kLdsScratch;
-  const size_t red_bytes = (size_t)8 * nh * 1024;
-  if ((size_t)nslot * kps * kb_bytes < red_bytes) ldsb = red_bytes + kLdsScratch;   // tiny K: the reduction buffer sets the size
-  dim3 grid(N / 16, cdiv(M, mt * 16));
-  if (mt == 2) {
-    if (pro) return launch_lds<T, 2, 8, true>(epi, grid, ldsb, st, x, w, M, N, K, fa, kps, nslot);
-    return launch_lds<T, 2, 8, false>(epi, grid, ldsb, st, x, w, M, N, K, fa, kps, nslot);
-  }
-  if (pro) return launch_lds<T, 1, 8, true>(epi, grid, ldsb, st, x, w, M, N, K, fa, kps, nslot);
-  return launch_lds<T, 1, 8, false>(epi, grid, ldsb, st, x, w, M, N, K, fa, kps, nslot);
-}
 
 // true if the fused kernel covers this shape (otherwise the caller uses the slab GEMM + separate epilogue kernels)
 template <typename T>
@@ -1015,8 +588,6 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
     set_error("gemm_fused: shape M=%d N=%d K=%d pro=%d epi=%d not covered", M, N, K, (int)pro, epi);
     return VLG_ERR_UNSUPPORTED;
   }
-  static const int lds_env = lds_knob("VLG_GEMM_LDS", 0);   // tools/microbench: force the LDS-DMA kernel without touching the callers
-  if ((fa.lds || lds_env) && gemm_lds_ok<T>(M, N, K, pro, epi) && !(fa.slabs && fa.counters)) return gemm_lds<T>(x, w, M, N, K, pro, epi, fa, st);
   int mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   const int nh = epi == EPI_SWIGLU ? 2 : 1;
   const int nkb_all = K / KB<T>::KBLK;
@@ -1024,22 +595,11 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
   // vector-memory pipe (the row halves of a tile share an XCD, see the kernel); 8 waves when K needs more than 16 K-block slots
   const bool rows16 = !pro && (epi == EPI_RESID || epi == EPI_GATED || epi == EPI_STORE) && mt == 2 && N / 16 <= 128 && (N / 16) % 8 == 0;
   if (rows16) mt = 1;
-  int splits = 1;
-  if (!pro && (epi == EPI_RESID || epi == EPI_STORE) && fa.slabs && fa.counters) {
-    // few n-tiles (N = D): K split over workgroups as well, combined in-launch by the last arriver
-    const int tiles = (N / 16) * cdiv(M, mt * 16);
-    splits = (320 + tiles / 2) / tiles;
-    const int maxs = nkb_all / 4;
-    if (splits > maxs) splits = maxs;
-    if (splits > 8) splits = 8;
-    if (splits < 1) splits = 1;
-    if (tiles > fa.max_tiles) splits = 1;
-  }
-  const bool wide = (mt * nh >= 4) || (rows16 && cdiv(nkb_all, splits) > 16);   // 8 waves so one pass of the K loop covers the slice
-  dim3 grid(N / 16, cdiv(M, mt * 16), splits);
+  const bool wide = (mt * nh >= 4) || (rows16 && nkb_all > 16);   // 8 waves so one pass of the K loop covers the slice
+  dim3 grid(N / 16, cdiv(M, mt * 16));
   // small batches (M <= 16: the per-GPU shards of a batch split over GPUs): the two N = D GEMMs on 8-column tiles, twice the workgroups
   static const int nc8_knob = lds_knob("VLG_GEMM_NC8", 1);
-  if (nc8_knob && !pro && epi == EPI_RESID && M <= 16 && splits == 1 && !fa.sq_out && N / 16 <= 128 && N % 8 == 0) {
+  if (nc8_knob && !pro && epi == EPI_RESID && M <= 16 && N / 16 <= 128 && N % 8 == 0) {
     grid = dim3(N / 8, 1, 1);
     if (nkb_all > 16)
       gemm_fused_kernel<T, 1, 8, false, EPI_RESID, 8><<<grid, 512, 0, st>>>(x, w, M, N, K, fa);

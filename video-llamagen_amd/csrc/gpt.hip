@@ -20,16 +20,14 @@
 using namespace vlg;
 
 struct Lane {
-  DevBuf kcache, vcache, ws, attn_ws, attn_cnt, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
+  DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
-  DevBuf counters;                                          // in-launch split-K arrival counters (zeroed once)
   DevBuf dp_xbuf;                                           // persistent DiffLoss sampler: exchange buffer
-  DevBuf rowsq;                                             // [D/16][64-padded rows] per-tile sums of squares of the residual stream (FusedGemm::sq_*)
   DevBuf maskbuf;                                           // this lane's rows of the caller's emb_mask (stable address for the cached graph)
   std::vector<uint64_t> ptr_key() const {                   // every address a captured decode step can hold
     std::vector<uint64_t> k;
-    for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &attn_cnt, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
-                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &counters, &maskbuf, &rowsq, &dp_xbuf})
+    for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
+                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &maskbuf, &dp_xbuf})
       k.push_back((uint64_t)(uintptr_t)b->p);
     return k;
   }
@@ -64,17 +62,18 @@ struct vlg_gpt {
   int kv_block = 0;                  // sessions: positions per KV block (0 = one contiguous slot of max length per row)
   int kv_pool_blocks = 0;            //           blocks in the pool, scratch block included (0 = enough for every row at full length)
   float cfg_iter = 1.0f;             // DiffLoss.sample's cfg (generate_video_diff.py:89-91): != 1 pairs rows b and b + B/2 inside the sampler
+  unsigned* fault_host = nullptr;    // pinned, device-visible fault word(s) of the persistent kernels (vlg_gpt_status)
+  unsigned* fault_dev = nullptr;
+  int spin_max = 0;                  // option debug_spin_max (0 = default bound)
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
-  // per-generate state: independent batch lanes (own activations, KV cache, state, stream)
-  std::vector<std::unique_ptr<Lane>> lanes;
+  // per-generate state: activations, KV cache, step state and the stream the decode loop runs on
+  Lane lane;
   struct Session;                    // iteration-level batching (vlg_gpt_session_*)
   std::unique_ptr<Session> ses;
-  int lanes_opt = 0;   // 0 = auto
-  int last_lanes = 1;
   hipStream_t s_int = nullptr;   // weight uploads
-  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_fork = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
   bool use_graph = true;
   // The instantiated decode-step graph of the last generate(), reused while every value and address baked into it is unchanged
   // (shape, sampling parameters, options, lane buffers, noise / trace pointers).  Outputs go through `outbuf` (handle-owned, stable
@@ -95,15 +94,8 @@ struct vlg_gpt {
   } gc;
   DevBuf outbuf;                     // [B, N] int32 ids or [B, N, C] fp32 latents of the running call
   long long graphs_built = 0;        // instantiations so far (tests: a repeated call must not add one)
-  bool attn_inlaunch = false;        // split-KV partials merged by the last-arriving workgroup instead of a combine launch
-                                     // (r01: 22.96 s vs 21.81 s/step - the ticket's round trip stalls every workgroup's exit)
-  bool splitk_inlaunch = false;      // residual GEMMs: K split over workgroups, combined in-launch by the last arriver
   bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
-  bool gemm_lds = false;             // decode GEMMs on the LDS-DMA kernel + row statistics handed from producer to consumer (r02: equal in the
-                                     // GEMM-chain microbenchmark, 8 % slower in the step at short context - DESIGN.md section 5 - so off)
-  bool fuse_qkv = false;             // decode: RoPE + KV append inside the attention kernel (r01: +4 us/layer vs the separate
-                                     // scatter kernel - 111 VGPRs and a dependent prologue - so off by default)
   bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
   std::vector<hipEvent_t> attn_ev;   // 2 per decode step
   double attn_ms_sum = 0, attn_bytes_sum = 0;
@@ -116,7 +108,7 @@ struct vlg_gpt {
     if (s_int) (void)hipStreamDestroy(s_int);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (fault_host) (void)hipHostFree(fault_host);
     for (auto e : attn_ev) (void)hipEventDestroy(e);
   }
   const void* W(const std::string& n) const { return w.at(n).buf.p; }
@@ -337,7 +329,9 @@ extern "C" int vlg_gpt_create(const vlg_gpt_config* cfg, vlg_gpt_t** out) {
   VLG_HIP(hipStreamCreateWithFlags(&h->s_int, hipStreamNonBlocking));
   VLG_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
   VLG_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
-  VLG_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  VLG_HIP(hipHostMalloc((void**)&h->fault_host, 64, hipHostMallocMapped));
+  memset(h->fault_host, 0, 64);
+  VLG_HIP(hipHostGetDevicePointer((void**)&h->fault_dev, h->fault_host, 0));
   *out = h.release();
   return VLG_OK;
 }
@@ -383,24 +377,12 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->time_attn = value != 0;
     return VLG_OK;
   }
-  if (!strcmp(key, "splitk_inlaunch")) {
-    h->splitk_inlaunch = value != 0;
-    return VLG_OK;
-  }
   if (!strcmp(key, "fuse_gemm")) {
     h->fuse_gemm = value != 0;
     return VLG_OK;
   }
-  if (!strcmp(key, "attn_inlaunch")) {
-    h->attn_inlaunch = value != 0;
-    return VLG_OK;
-  }
   if (!strcmp(key, "fuse_swiglu")) {
     h->fuse_swiglu = value != 0;
-    return VLG_OK;
-  }
-  if (!strcmp(key, "fuse_qkv")) {
-    h->fuse_qkv = value != 0;
     return VLG_OK;
   }
   if (!strcmp(key, "kv_block")) {
@@ -413,23 +395,29 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->kv_pool_blocks = (int)value;
     return VLG_OK;
   }
+  if (!strcmp(key, "debug_spin_max")) {
+    VLG_CHECK(value >= 0 && value <= (1 << 24), VLG_ERR_BAD_ARG, "debug_spin_max out of range");
+    h->spin_max = (int)value;
+    return VLG_OK;
+  }
   if (!strcmp(key, "dl_persist")) {
     h->dl_persist_on = value != 0;
     return VLG_OK;
   }
-  if (!strcmp(key, "gemm_lds")) {
-    h->gemm_lds = value != 0;
-    return VLG_OK;
-  }
-  if (!strcmp(key, "lanes")) {
-    // at most 2: more lanes never paid off, and the HIP runtime (7.0 / 7.2) crashes in hip::Graph::UpdateStreams when a
-    // graph with more parallel branches than an earlier graph of the process is launched (2 -> 4 lanes on one handle)
-    VLG_CHECK(value >= 0 && value <= 2, VLG_ERR_BAD_ARG, "lanes must be 0 (auto), 1 or 2");
-    h->lanes_opt = (int)value;
-    return VLG_OK;
-  }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
+}
+
+// a pending device-side fault (time-out inside a persistent kernel): report + clear
+static int collect_fault(vlg_gpt* h) {
+  const unsigned f = __atomic_load_n(h->fault_host, __ATOMIC_ACQUIRE);
+  if (f == 0) return VLG_OK;
+  __atomic_store_n(h->fault_host, 0u, __ATOMIC_RELEASE);
+  const unsigned kind = f & 0xffff0000u;
+  set_error("device fault 0x%08x: an in-launch wait of the %s ran out (index %u) - the grid was not fully resident (another kernel held compute "
+            "units?) or debug_spin_max forced it; the results of that call are invalid",
+            f, kind == kFaultDlPersist ? "persistent DiffLoss sampler" : (kind == kFaultDecode ? "persistent decode step" : "persistent kernel"), f & 0xffffu);
+  return VLG_ERR_STATE;
 }
 
 extern "C" int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count) {
@@ -462,11 +450,9 @@ extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* 
 
 namespace {
 
-constexpr int kMaxTiles = 4096;   // arrival counters per lane for the in-launch split-K GEMMs
-
-// One lane = an independent slice of the batch with its own activations, KV cache, step state and stream.
-// Lanes share the weights.  Two lanes on forked graph branches let one lane's latency-bound kernels (skinny GEMMs,
-// norms, RoPE) run under the other lane's HBM-bound attention.
+// A Runner drives one set of buffers (Lane: activations, KV cache, step state, stream) through prefill / decode steps.  b0 / Btot
+// place its rows inside a larger call (sessions prefill one slot at a time).  Splitting a batch into concurrent lanes on forked graph
+// branches was measured slower in rounds 1 and 2 and is gone.
 template <typename T>
 struct Runner {
   vlg_gpt* h;
@@ -488,7 +474,6 @@ struct Runner {
   }
   size_t kv_off() const { return pages.table ? 0 : (size_t)kv_row0 * h->H * S * h->hd; }
   StepState* state() { return ln->state.as<StepState>(); }
-  int* attn_cnt() { return h->attn_inlaunch ? ln->attn_cnt.as<int>() : nullptr; }
   template <typename U>
   const U* W(const std::string& n) {
     return reinterpret_cast<const U*>(h->W(n));
@@ -514,15 +499,14 @@ struct Runner {
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
       T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
       VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
-      const bool fused = (Tq == 1) && h->fuse_qkv && pages.table == nullptr;
-      if (!fused) VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos, pages));
+      VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos, pages));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
-                           h->Tc, st, e0, e1, fused ? ws : nullptr, sp, h->freqs.as<float>(), attn_cnt(), row_pos, pages));
+                           h->Tc, st, e0, e1, row_pos, pages));
       VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
@@ -561,27 +545,14 @@ struct Runner {
     }
     VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, norm_w, ln->xn.as<T>(), Bp, K, h->cfg.norm_eps, st));
     fa.norm_w = nullptr;
-    fa.sq_in = nullptr;
     return gemm_fused<T>(ln->xn.as<T>(), w, Bp, Nn, K, false, epi, fa, st);
   }
 
   // x [Bp, D] = residual stream (token / latent embeddings); on return x holds the last layer's output, NOT normed
-  // Row statistics travel with the residual stream when all four layer GEMMs run on the LDS-DMA kernel (gemm_fused.hip): the kernel
-  // that writes x leaves per-tile sums of squares in `rowsq`, the RMSNorm prologue of the next kernel sums them.
-  bool stats_ok() {
-    const int D = h->D, F = h->F;
-    return h->gemm_lds && gemm_lds_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_lds_ok<T>(Bp, D, D, false, EPI_RESID) && gemm_lds_ok<T>(Bp, F, D, true, EPI_SWIGLU) &&
-           gemm_lds_ok<T>(Bp, D, F, false, EPI_RESID) && !h->splitk_inlaunch && D % 16 == 0;
-  }
-  bool x_has_stats = false;   // rowsq describes the current contents of x
-
   int layers_fused() {
     const int M = Bp, D = h->D, H = h->H, hd = h->hd, F = h->F;
     T* x = ln->x.as<T>();
     const size_t lstride = kv_lstride();
-    const bool stats = stats_ok();
-    const int sq_stride = round_up(Bp, 64);
-    float* rowsq = ln->rowsq.as<float>();
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
@@ -598,12 +569,6 @@ struct Runner {
       fa.H = H;
       fa.hd = hd;
       fa.S = S;
-      fa.lds = h->gemm_lds;
-      if (stats && (l > 0 || x_has_stats)) {
-        fa.sq_in = rowsq;
-        fa.sq_tiles = D / 16;
-        fa.sq_stride = sq_stride;
-      }
       VLG_TRY(norm_gemm(x, W<T>(p + "attention_norm.weight"), W<T>(p + "attention.wqkv.weight"), 3 * D, D, EPI_QKV, fa));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
@@ -611,32 +576,15 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
-                           st, e0, e1, nullptr, 0, nullptr, attn_cnt(), row_pos, pages));
+                           st, e0, e1, row_pos, pages));
       FusedGemm fr;
       fr.h = x;
-      fr.lds = h->gemm_lds;
-      if (h->splitk_inlaunch) {   // measured r01: the release/acquire pair costs more than the idle CUs (22.9 s vs 22.6 s/step)
-        fr.slabs = ln->ws.as<float>();
-        fr.counters = ln->counters.as<int>();
-        fr.max_tiles = kMaxTiles;
-      }
-      if (stats) {
-        fr.sq_out = rowsq;
-        fr.sq_stride = sq_stride;
-      }
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
       fs.out = ln->g.as<T>();
-      fs.lds = h->gemm_lds;
-      if (stats) {
-        fs.sq_in = rowsq;
-        fs.sq_tiles = D / 16;
-        fs.sq_stride = sq_stride;
-      }
       VLG_TRY(norm_gemm(x, W<T>(p + "ffn_norm.weight"), W<T>(p + "feed_forward.w13"), F, D, EPI_SWIGLU, fs));
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
     }
-    x_has_stats = stats;
     return VLG_OK;
   }
 
@@ -645,13 +593,6 @@ struct Runner {
     const int D = h->D;
     FusedGemm fa;
     const T* final_norm = W<T>("norm.weight");
-    fa.lds = h->gemm_lds;
-    if (x_has_stats) {
-      fa.sq_in = ln->rowsq.as<float>();
-      fa.sq_tiles = D / 16;
-      fa.sq_stride = round_up(Bp, 64);
-    }
-    x_has_stats = false;
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       fa.out_f32 = ln->logits.as<float>();
       VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("output.weight"), h->V, D, EPI_STORE, fa));
@@ -769,14 +710,13 @@ struct Runner {
     }
     const T* wip = W<T>(p + "input_proj.weight");
     const T* bip = W<T>(p + "input_proj.bias");
-    // one lane only: two persistent launches on concurrent branches could each hold half of the CUs and wait for the other half
     const bool dcfg = h->cfg_iter != 1.0f;   // forward_with_cfg: the launch chain below (the persistent kernel keeps rows independent)
     const int n_half = dcfg ? B / 2 : 0;
-    if (dcfg && (B % 2 != 0 || h->last_lanes != 1)) {
-      set_error("cfg_iter != 1 pairs row b with row b + B/2 (diffloss.py:38-39): it needs an even batch on one lane, got %d rows", B);
+    if (dcfg && B % 2 != 0) {
+      set_error("cfg_iter != 1 pairs row b with row b + B/2 (diffloss.py:38-39): it needs an even batch, got %d rows", B);
       return VLG_ERR_BAD_SHAPE;
     }
-    if (h->dl_persist_on && !dcfg && h->last_lanes == 1 && dl_persist_ok<T>(B, Wd, C, dd)) {
+    if (h->dl_persist_on && !dcfg && dl_persist_ok<T>(B, Wd, C, dd)) {
       // all S reverse steps in one persistent launch (2 depth all-gathers per step between the workgroups of a 4-row group)
       DlPersist dp{};
       for (int blk = 0; blk < dd; ++blk) {
@@ -803,6 +743,8 @@ struct Runner {
       dp.depth = dd; dp.W = Wd; dp.C = C; dp.S = S; dp.B = B; dp.MR = MR; dp.N = N; dp.b_off = b0; dp.B_total = Btot;
       dp.temperature = sp.temperature;
       dp.seed = sp.seed;
+      dp.fault = h->fault_dev;
+      dp.spin_max = h->spin_max > 0 ? h->spin_max : (1 << 20);
       return dl_persist<T>(dp, st);
     }
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
@@ -895,13 +837,6 @@ struct Runner {
       VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
       FusedGemm f2;
       f2.out = ln->x.as<T>();
-      f2.lds = h->gemm_lds;
-      x_has_stats = false;
-      if (stats_ok() && fused_decode_ok() && gemm_lds_ok<T>(Bp, D, D, false, EPI_STORE)) {   // the first layer's norm finds its sums ready
-        f2.sq_out = ln->rowsq.as<float>();
-        f2.sq_stride = round_up(Bp, 64);
-        x_has_stats = true;
-      }
       VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
     } else if (h->cfg.model_type == VLG_T2V) {
       VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
@@ -998,10 +933,6 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   }
   VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
-  if (ln.attn_cnt.bytes < (size_t)M * H * sizeof(int)) {   // arrival counters: zero once, every launch leaves them zero
-    VLG_TRY(ln.attn_cnt.reserve((size_t)M * H * sizeof(int)));
-    VLG_HIP(hipMemset(ln.attn_cnt.p, 0, ln.attn_cnt.bytes));
-  }
   VLG_TRY(ln.x.reserve((size_t)M * D * e));
   VLG_TRY(ln.xn.reserve((size_t)M * D * e));
   VLG_TRY(ln.q.reserve((size_t)M * D * e));
@@ -1018,14 +949,6 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
   VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
   VLG_TRY(ln.state.reserve(sizeof(StepState)));
-  VLG_TRY(ln.rowsq.reserve((size_t)(D / 16 + 1) * round_up(Bp, 64) * sizeof(float)));
-  if (ln.counters.bytes == 0) {
-    VLG_TRY(ln.counters.reserve(kMaxTiles * sizeof(int)));
-    VLG_HIP(hipMemset(ln.counters.p, 0, kMaxTiles * sizeof(int)));
-  }
-  // fused split-K tile slabs live in ws: tiles * splits * MT*256 floats <= 8 * (Bp rounded to 64) * N
-  wsf = std::max(wsf, (size_t)8 * (size_t)round_up(Bp, 64) * (size_t)std::max(D, F));
-  VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   if (!ln.st) VLG_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
   if (!ln.ev) VLG_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
   return VLG_OK;
@@ -1043,12 +966,6 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     VLG_CHECK(Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
   for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
 
-  // ---- lanes: contiguous sample ranges, each with its own buffers (grow-only) and stream -------------------
-  int nl = h->lanes_opt;
-  if (nl <= 0) nl = 1;   // auto: measured on MI355X (r01): kernels of two lanes do not overlap enough to pay for streaming the weights twice
-  if (nl > B) nl = B;
-  if (nl > 2) nl = 2;
-  while ((int)h->lanes.size() < nl) h->lanes.emplace_back(new Lane());
   const bool latent_out = h->cfg.head != VLG_HEAD_LOGITS;
   const size_t out_bytes = latent_out ? (size_t)B * N * h->C * sizeof(float) : (size_t)B * N * sizeof(int32_t);
   void* user_out = latent_out ? (void*)out_lat : (void*)out_ids;
@@ -1057,52 +974,43 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     out_lat = h->outbuf.as<float>();
   else
     out_ids = h->outbuf.as<int32_t>();
-  std::vector<Runner<T>> rs;
-  for (int i = 0; i < nl; ++i) {
-    const int lo = (int)((long long)B * i / nl), hi = (int)((long long)B * (i + 1) / nl);
-    const int Bl = hi - lo, Bpl = cfg_on ? 2 * Bl : Bl;
-    Lane* ln = h->lanes[i].get();
-    VLG_TRY(reserve_lane(h, *ln, Bl, Bpl, S));
-    if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)Bl * Tc * sizeof(float)));
-    rs.push_back(Runner<T>{h, ln, ln->st, Bl, Bpl, N, S, lo, B, d_mask ? ln->maskbuf.as<float>() : nullptr});
-  }
-  h->last_lanes = nl;
+  Lane* ln = &h->lane;
+  VLG_TRY(reserve_lane(h, *ln, B, cfg_on ? 2 * B : B, S));
+  if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)B * Tc * sizeof(float)));
+  Runner<T> r{h, ln, ln->st, B, cfg_on ? 2 * B : B, N, S, 0, B, d_mask ? ln->maskbuf.as<float>() : nullptr};
   if (h->cfg.head == VLG_HEAD_HIDDEN) {
     VLG_CHECK(!cfg_on, VLG_ERR_UNSUPPORTED, "the DiffLoss head runs with cfg_scale = 1 only (generate_video_diff.py:112-137 never assigns the CFG branch)");
-    if (!h->dtemb_ready) VLG_TRY(rs[0].build_time_table());
+    if (!h->dtemb_ready) VLG_TRY(r.build_time_table());
   }
 
   // ---- fork from the caller's stream ----------------------------------------------------------------------------
   VLG_HIP(hipEventRecord(h->ev_in, caller));
-  for (auto& r : rs) {
-    VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
-    if (d_mask)
-      VLG_HIP(hipMemcpyAsync(r.ln->maskbuf.p, d_mask + (size_t)r.b0 * Tc, (size_t)r.B * Tc * sizeof(float), hipMemcpyDeviceToDevice, r.st));
-  }
-  for (auto& r : rs) VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
-  hipStream_t s0 = rs[0].st;
+  VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
+  if (d_mask) VLG_HIP(hipMemcpyAsync(ln->maskbuf.p, d_mask, (size_t)B * Tc * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
+  hipStream_t s0 = r.st;
   const int steps = N - 1;
   if (steps > 0) {
     if (h->time_attn) {
-      // eager loop on every lane's stream; HIP events (on lane 0's stream) around lane 0 / layer 0's attention kernel
+      // eager loop; HIP events (on the launch stream) around layer 0's attention kernel
       while ((int)h->attn_ev.size() < 2 * steps) {
         hipEvent_t ev;
         VLG_HIP(hipEventCreate(&ev));
         h->attn_ev.push_back(ev);
       }
       for (int i = 0; i < steps; ++i) {
-        rs[0].ev_slot = i;
-        for (auto& r : rs) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+        r.ev_slot = i;
+        VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
       }
-      rs[0].ev_slot = -1;
-      for (auto& r : rs) VLG_HIP(hipStreamSynchronize(r.st));
+      r.ev_slot = -1;
+      VLG_HIP(hipStreamSynchronize(r.st));
       h->attn_ms_sum = 0;
       h->attn_bytes_sum = 0;
       for (int i = 0; i < steps; ++i) {
         float ms = 0.f;
         VLG_HIP(hipEventElapsedTime(&ms, h->attn_ev[2 * i], h->attn_ev[2 * i + 1]));
         h->attn_ms_sum += ms;
-        h->attn_bytes_sum += 2.0 * rs[0].Bp * D * (double)(Tc + i + 1) * h->esz;  // K and V rows 0..p of one layer, lane 0
+        h->attn_bytes_sum += 2.0 * r.Bp * D * (double)(Tc + i + 1) * h->esz;  // K and V rows 0..p of one layer
       }
       h->attn_launches = steps;
       // what the bracket itself costs: back-to-back event pairs with nothing between them, same stream, same session
@@ -1122,25 +1030,21 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
         h->attn_pair_overhead_ms = ncal > 0 ? tot / ncal : 0.0;
       }
     } else if (h->use_graph) {
-      // one graph = one decode step of every lane, lanes on parallel branches (fork/join on lane 0's stream)
-      for (size_t i = 1; i < rs.size(); ++i) {  // order the other lanes' prefill before the graph launches
-        VLG_HIP(hipEventRecord(rs[i].ln->ev, rs[i].st));
-        VLG_HIP(hipStreamWaitEvent(s0, rs[i].ln->ev, 0));
-      }
+      // one graph = one decode step
       auto fbits = [](float f) {
         uint32_t u;
         memcpy(&u, &f, 4);
         return (uint64_t)u;
       };
-      std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)N, (uint64_t)nl, (uint64_t)S, (uint64_t)h->dtype, fbits(sp.cfg_scale),
+      std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)N, (uint64_t)S, (uint64_t)h->dtype, fbits(sp.cfg_scale),
                                    (uint64_t)(int64_t)sp.cfg_interval, fbits(sp.temperature), (uint64_t)(int64_t)sp.top_k, fbits(sp.top_p),
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
-                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->fuse_qkv ? 4 : 0) | (h->attn_inlaunch ? 8 : 0) |
-                                              (h->splitk_inlaunch ? 16 : 0) | (d_mask ? 32 : 0) | (h->gemm_lds ? 64 : 0) | (h->dl_persist_on ? 128 : 0)), (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter)};
-      for (auto& r : rs) {
-        key.push_back((uint64_t)(uintptr_t)r.st);
-        const auto pk = r.ln->ptr_key();
+                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
+                                   (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
+                                   (uint64_t)h->spin_max};
+      {
+        const auto pk = ln->ptr_key();
         key.insert(key.end(), pk.begin(), pk.end());
       }
       if (!h->gc.exec || h->gc.key != key) {
@@ -1148,23 +1052,12 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         VLG_HIP(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
-        int rc = VLG_OK;
-        hipError_t ce = hipSuccess;
-        if (rs.size() > 1) {
-          ce = hipEventRecord(h->ev_fork, s0);
-          for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) ce = hipStreamWaitEvent(rs[i].st, h->ev_fork, 0);
-        }
-        for (size_t i = 0; i < rs.size() && rc == VLG_OK && ce == hipSuccess; ++i) rc = rs[i].decode_step(sp, d_noise, out_ids, out_lat, trace);
-        for (size_t i = 1; i < rs.size() && ce == hipSuccess; ++i) {
-          ce = hipEventRecord(rs[i].ln->ev, rs[i].st);
-          if (ce == hipSuccess) ce = hipStreamWaitEvent(s0, rs[i].ln->ev, 0);
-        }
+        const int rc = r.decode_step(sp, d_noise, out_ids, out_lat, trace);
         hipError_t ee = hipStreamEndCapture(s0, &graph);
         if (rc != VLG_OK) {
           if (graph) (void)hipGraphDestroy(graph);
           return rc;
         }
-        VLG_HIP(ce);
         VLG_HIP(ee);
         hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (ie != hipSuccess) {
@@ -1179,15 +1072,12 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
       }
       for (int i = 0; i < steps; ++i) VLG_HIP(hipGraphLaunch(h->gc.exec, s0));   // no host wait: the call returns with the work enqueued
     } else {
-      for (int i = 0; i < steps; ++i)
-        for (auto& r : rs) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
+      for (int i = 0; i < steps; ++i) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
     }
   }
   // ---- join back into the caller's stream ---------------------------------------------------------------------------
-  for (auto& r : rs) {
-    VLG_HIP(hipEventRecord(r.ln->ev, r.st));
-    VLG_HIP(hipStreamWaitEvent(caller, r.ln->ev, 0));
-  }
+  VLG_HIP(hipEventRecord(ln->ev, r.st));
+  VLG_HIP(hipStreamWaitEvent(caller, ln->ev, 0));
   VLG_HIP(hipMemcpyAsync(user_out, h->outbuf.p, out_bytes, hipMemcpyDeviceToDevice, caller));
 
   // ---- algorithmic bytes of this call; weights are streamed once per lane and step ------------------
@@ -1326,29 +1216,40 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   const int R = s.R, null_cls = h->cfg.num_classes;
   const bool text = h->cfg.model_type != VLG_C2I;
   const int first = h->Tc - 1;         // input position of the step that samples token 0 (the last condition token)
+  // pass 1: validate every slot's code; nothing is changed before the whole step is known to be well-formed (a failure for slot b must
+  // not leave slots < b advanced with nothing launched)
   for (int b = 0; b < R; ++b) {
     const int c = h_row_class[b];
-    int cls = -1, cls_partner = -1;
     if (s.paged() && (c >= 0 || c == -3 || (c == -1 && s.pos[b] >= 0))) {
       const int next = (c == -1) ? s.pos[b] + 1 : (text ? first : 0);
       VLG_CHECK(next < s.reserved[b], VLG_ERR_STATE, "slot %d: position %d is outside its reserved KV blocks (%d positions; vlg_gpt_session_reserve)",
                 b, next, s.reserved[b]);
     }
-    if (c >= 0 && !text) {             // start a class-conditional request in this slot
+    if (c >= 0 && !text) {
       VLG_CHECK(c <= null_cls, VLG_ERR_BAD_ARG, "class id %d out of range", c);
+    } else if (c == -3 && text) {
+      VLG_CHECK(s.prefilled[b], VLG_ERR_STATE, "slot %d has no prefilled condition", b);
+    } else if (c == -1 && s.pos[b] >= 0) {
+      VLG_CHECK(s.pos[b] + 1 < first + s.maxN, VLG_ERR_BAD_SHAPE, "slot %d stepped past max_new_tokens %d", b, s.maxN);
+    } else {
+      VLG_CHECK(c < 0, VLG_ERR_BAD_ARG, "slot %d: start code %d does not fit this model type", b, c);
+    }
+  }
+  // pass 2: advance the host mirror
+  for (int b = 0; b < R; ++b) {
+    const int c = h_row_class[b];
+    int cls = -1, cls_partner = -1;
+    if (c >= 0 && !text) {             // start a class-conditional request in this slot
       s.pos[b] = 0;
       cls = c;
       cls_partner = null_cls;          // unconditional partner row: null class at the start (generate.py:131)
     } else if (c == -3 && text) {      // start the request whose condition vlg_gpt_session_prefill put into this slot
-      VLG_CHECK(s.prefilled[b], VLG_ERR_STATE, "slot %d has no prefilled condition", b);
       s.prefilled[b] = 0;
       s.pos[b] = first;
       cls = cls_partner = -3;          // input row = the projected last condition token (cond / uncond), left in `pending`
     } else if (c == -1 && s.pos[b] >= 0) {   // continue
       s.pos[b] += 1;
-      VLG_CHECK(s.pos[b] < first + s.maxN, VLG_ERR_BAD_SHAPE, "slot %d stepped past max_new_tokens %d", b, s.maxN);
     } else {                           // idle (or told to stop): park the slot at position 0 on the null class / a zero row
-      VLG_CHECK(c < 0, VLG_ERR_BAD_ARG, "slot %d: start code %d does not fit this model type", b, c);
       s.pos[b] = -1;
       cls = cls_partner = text ? -3 : null_cls;
       if (text && s.prefilled[b]) cls = cls_partner = -1;   // do not step on a waiting slot's KV row 0: feed a token row at ITS position
@@ -1400,6 +1301,8 @@ int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float*
   const int Tc = h->Tc, D = h->D, cd = h->cd;
   hipStream_t st = s.ln.st;
   float* mrow = s.maskbuf.as<float>() + (size_t)slot * Tc;
+  if (s.paged()) VLG_CHECK(s.reserved[slot] >= Tc, VLG_ERR_STATE, "slot %d: reserve its KV blocks first (vlg_gpt_session_reserve)", slot);
+  s.pos[slot] = -1;   // arguments are valid: whatever ran in the slot is over, the caller reuses it (its tokens were read with session_read)
   if (d_mask) {
     VLG_HIP(hipMemcpyAsync(mrow, d_mask, (size_t)Tc * sizeof(float), hipMemcpyDeviceToDevice, st));
   } else {
@@ -1408,7 +1311,6 @@ int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float*
     VLG_HIP(hipStreamSynchronize(st));
   }
   if (s.paged()) {
-    VLG_CHECK(s.reserved[slot] >= Tc, VLG_ERR_STATE, "slot %d: reserve its KV blocks first (vlg_gpt_session_reserve)", slot);
     if (s.btab_dirty) {
       VLG_HIP(hipMemcpyAsync(s.btab.p, s.h_btab.data(), s.h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
       VLG_HIP(hipStreamSynchronize(st));
@@ -1440,7 +1342,6 @@ extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* 
   VLG_CHECK(h->ses != nullptr, VLG_ERR_STATE, "no open session");
   VLG_CHECK(h->cfg.model_type == VLG_T2I, VLG_ERR_UNSUPPORTED, "vlg_gpt_session_prefill is for text-conditioned token models");
   VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
-  h->ses->pos[slot] = -1;   // whatever ran in the slot is over: the caller reuses it (its tokens were read with session_read)
   return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
 }
 
@@ -1542,11 +1443,21 @@ extern "C" int vlg_gpt_session_end(vlg_gpt_t* h) {
   return VLG_OK;
 }
 
+extern "C" int vlg_gpt_status(vlg_gpt_t* h, int32_t sync) {
+  VLG_CHECK(h, VLG_ERR_BAD_ARG, "vlg_gpt_status: null handle");
+  if (sync) {
+    if (h->lane.st) VLG_HIP(hipStreamSynchronize(h->lane.st));
+    if (h->ses && h->ses->ln.st) VLG_HIP(hipStreamSynchronize(h->ses->ln.st));
+  }
+  return collect_fault(h);
+}
+
 extern "C" int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, int32_t B, int32_t N,
                                 const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids, float* d_out_lat,
                                 float* d_trace, void* stream) {
   VLG_CHECK(h && d_cond && sp, VLG_ERR_BAD_ARG, "vlg_gpt_generate: null argument");
   VLG_CHECK(B > 0 && N > 0, VLG_ERR_BAD_ARG, "vlg_gpt_generate: B and N must be positive");
+  VLG_TRY(collect_fault(h));   // an earlier call's time-out nobody asked about
   if (h->cfg.head == VLG_HEAD_LOGITS)
     VLG_CHECK(d_out_ids, VLG_ERR_BAD_ARG, "vlg_gpt_generate: d_out_ids is required for the logits head");
   else

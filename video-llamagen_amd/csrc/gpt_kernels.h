@@ -60,19 +60,6 @@ struct FusedGemm {
   float* out_f32 = nullptr;       // EPI_STORE
   const void* bias = nullptr;     // EPI_STORE (dtype T)
   int act = 0;
-  // optional in-launch split-K (EPI_RESID / EPI_STORE without prologue): fp32 tile slabs [tiles][splits][MT*256] and one
-  // arrival counter per tile (zero at allocation; the last arriver resets it)
-  float* slabs = nullptr;
-  int* counters = nullptr;
-  int max_tiles = 0;
-  // Row statistics handed from the kernel that WRITES the residual stream to the PRO (RMSNorm) kernel that reads it next, so the
-  // consumer does not need its rows resident to normalise them: sq[t * sq_stride + row] = sum over the 16 columns of n-tile t of
-  // (stored value)^2.  sq_out: EPI_RESID / EPI_STORE producers (N / 16 tiles); sq_in: PRO consumers (sq_tiles = K / 16 partials per
-  // row, summed in tile order: deterministic).  sq_in == nullptr: the consumer computes the sums itself from x (one more pass).
-  float* sq_out = nullptr;
-  const float* sq_in = nullptr;
-  int sq_tiles = 0, sq_stride = 0;
-  bool lds = false;               // run on the LDS-DMA kernel (gemm_lds_kernel) where it covers the shape; off by default
 #ifdef VLG_KTRACE
   unsigned long long* trace = nullptr;   // tools/microbench only: 4 timestamps per workgroup
 #endif
@@ -81,9 +68,6 @@ template <typename T>
 bool gemm_fused_ok(int M, int N, int K, bool pro, int epi);
 template <typename T>
 int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, const FusedGemm& fa, hipStream_t st);
-// true if gemm_fused would run this shape on the LDS-DMA kernel (which is the one that honours sq_out / sq_in)
-template <typename T>
-bool gemm_lds_ok(int M, int N, int K, bool pro, int epi);
 
 // LayerNorm + adaLN-modulate prologue (DiffLoss ResBlock / FinalLayer, diffloss.py:55-56,120-128,141-148) fused into the skinny GEMM:
 //   out = rt(act(rt(bias + W . rt(rt(LN(x) [* ln_w + ln_b]) * (1 + scale[row]) + shift[row]))))
@@ -128,16 +112,10 @@ int qkv_rope_scatter(const float* ws, int splits, T* qbuf, T* kcache, T* vcache,
 // attention of every query row m = b*Tq + t (position p = state->pos + t) over keys 0..p of batch b
 // (gpt.py:230-237 with the mask of generate.py:156-165).  out [M, H*hd].
 // mask: fp32 [Bmask, Tc] or null; batch row b uses mask row b % Bmask.
-// qkv_ws != null (decode, Tq == 1 only): fused mode - q/k/v come from the QKV GEMM slabs [qkv_splits][M][3D], RoPE and the
-// KV-cache append happen inside the attention kernel (qbuf unused, no qkv_rope_scatter launch).
 template <typename T>
 int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, const StepState* state,
               int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,  // ev0/ev1 bracket the split-KV kernel
-              const float* qkv_ws = nullptr, int qkv_splits = 0, const float* freqs = nullptr,
-              // counters != null: the splits are merged inside the launch by the last-arriving workgroup of each (row, head)
-              // (no attn_combine launch).  M*H ints, zero before the first launch; every launch leaves them zero.
-              int* counters = nullptr,
               const int32_t* row_pos = nullptr,    // sessions: batch row b attends keys 0..row_pos[b] (+t)
               KvPages pages = KvPages{});          // sessions with a block-granular cache
 size_t attn_ws_floats(int M, int H, int hd);
@@ -220,7 +198,11 @@ struct DlPersist {
   int depth, W, C, S, B, MR, N, b_off, B_total;
   float temperature;
   uint64_t seed;
+  unsigned* fault;       // host-visible fault word of the handle (vlg_gpt_status): set when an exchange wait runs out
+  int spin_max;          // spin bound of every wait (default 1 << 20; option debug_spin_max)
 };
+constexpr unsigned kFaultDlPersist = 0x444C0000u;   // 'DL' | reverse step index
+constexpr unsigned kFaultDecode = 0x50440000u;      // 'PD' | phase index
 size_t dl_persist_xbuf_bytes(int B, int W, int esz);
 template <typename T>
 bool dl_persist_ok(int B, int W, int C, int depth);

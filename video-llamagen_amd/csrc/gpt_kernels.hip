@@ -638,25 +638,13 @@ template int qkv_rope_scatter<bf16>(const float*, int, bf16*, bf16*, bf16*, cons
 //   with the usual (m, l, acc) rescale.
 // ------------------------------------------------------------------------------------------------
 
-// FUSED (decode, Tq == 1): the kernel consumes the QKV GEMM's fp32 slabs directly - it sums the split-K partials of its own
-// (row, head) slice, applies RoPE to q and to the new key (gpt.py:221-222), and the workgroup whose key range contains
-// position p writes the new K/V row into the cache (gpt.py:182-183) while using the in-register copy for its own
-// score - one kernel less per layer and no q buffer round trip.
-struct FusedQKV {
-  const float* ws;      // [splits][M][3*H*HD]
-  int splits;
-  const float* freqs;   // [npos][HD/2][2]
-};
-
 // PAGED: block-granular cache (KvPages); the batch row's block table is staged in LDS and every cache row address goes through it.
-template <typename T, int HD, int VEC, int LPR, bool FUSED, int U, bool PAGED = false>
+template <typename T, int HD, int VEC, int LPR, int U, bool PAGED = false>
 __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__ qbuf, T* __restrict__ kc,
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
-                                                           int Tc, float scale, FusedQKV fq, int* __restrict__ counters,
-                                                           const int32_t* __restrict__ row_pos, KvPages pg = KvPages{}) {
-  static_assert(!(PAGED && FUSED), "the fused-QKV form appends to a contiguous cache");
+                                                           int Tc, float scale, const int32_t* __restrict__ row_pos, KvPages pg = KvPages{}) {
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
@@ -673,43 +661,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
   const int coff = active ? c * VEC : 0;
 
   float qf[VEC];
-  Pack<T, VEC> knew, vnew;
-  bool own_p = false;
-  if constexpr (FUSED) {
-    static_assert(VEC % 2 == 0, "RoPE pairs must stay inside one lane");
-    const int M = gridDim.z, D3 = 3 * H * HD;
-    own_p = (r0 <= p && p < r1);
-    // unconditional, vectorised slab reads (every workgroup sums q, k and v: a per-element "load or not" select makes
-    // hipcc branch around each load and serialise them - cdna_hip_programming.md §5 trap (c))
-    float sq[VEC], sk[VEC], sv[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) sq[j] = sk[j] = sv[j] = 0.f;
-    for (int k = 0; k < fq.splits; ++k) {
-      const float* row = fq.ws + ((size_t)k * M + m) * D3 + h * HD + coff;
-      const Pack<float, VEC> pq = *reinterpret_cast<const Pack<float, VEC>*>(row);
-      const Pack<float, VEC> pk = *reinterpret_cast<const Pack<float, VEC>*>(row + H * HD);
-      const Pack<float, VEC> pv = *reinterpret_cast<const Pack<float, VEC>*>(row + 2 * H * HD);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        sq[j] += pq.v[j];
-        sk[j] += pk.v[j];
-        sv[j] += pv.v[j];
-      }
-    }
-    const float* fr = fq.freqs + ((size_t)p * (HD / 2) + coff / 2) * 2;
-#pragma unroll
-    for (int j = 0; j < VEC; j += 2) {
-      const float c = fr[j], sn = fr[j + 1];
-      const float q0 = DT<T>::rt(sq[j]), q1 = DT<T>::rt(sq[j + 1]);
-      qf[j] = active ? DT<T>::rt(__fsub_rn(__fmul_rn(q0, c), __fmul_rn(q1, sn))) : 0.f;
-      qf[j + 1] = active ? DT<T>::rt(__fadd_rn(__fmul_rn(q1, c), __fmul_rn(q0, sn))) : 0.f;
-      const float k0 = DT<T>::rt(sk[j]), k1 = DT<T>::rt(sk[j + 1]);
-      DT<T>::st(&knew.v[j], __fsub_rn(__fmul_rn(k0, c), __fmul_rn(k1, sn)));
-      DT<T>::st(&knew.v[j + 1], __fadd_rn(__fmul_rn(k1, c), __fmul_rn(k0, sn)));
-      DT<T>::st(&vnew.v[j], sv[j]);
-      DT<T>::st(&vnew.v[j + 1], sv[j + 1]);
-    }
-  } else {
+  {
     const Pack<T, VEC> qp = *reinterpret_cast<const Pack<T, VEC>*>(qbuf + ((size_t)m * H + h) * HD + coff);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) qf[j] = active ? DT<T>::ld(&qp.v[j]) : 0.f;
@@ -744,19 +696,6 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
       const size_t ro = rowoff(rr);
       kk[u] = load_stream<T, VEC>(kbase + ro);
       vv[u] = load_stream<T, VEC>(vbase + ro);
-      if constexpr (FUSED) {
-        // row p (the row this step appends) is not in the cache yet: every lane that addresses it - its owner and the
-        // out-of-range lanes clamped onto it - takes the in-register copy (stale cache bits could be NaN: 0 * NaN);
-        // the owner publishes it.
-        if (own_p && rr == p) {
-          kk[u] = knew;
-          vv[u] = vnew;
-          if (active && rows[u] == p) {
-            *reinterpret_cast<Pack<T, VEC>*>(kbase + (size_t)p * HD) = knew;
-            *reinterpret_cast<Pack<T, VEC>*>(vbase + (size_t)p * HD) = vnew;
-          }
-        }
-      }
     }
     float s[U];
     float tmax = -INFINITY;
@@ -825,47 +764,12 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
       DT<T>::st(out + ((size_t)m * H + h) * HD + d, A / L);
     } else {
       float* o = ws + (((size_t)m * H + h) * nsplit + split) * (HD + 2);
-      if (counters == nullptr) {
-        o[2 + d] = A;
-        if (d == 0) {
-          o[0] = M4;
-          o[1] = L;
-        }
-      } else {   // in-launch merge: write-through (sc1) stores, read back with sc1 loads - no cache-wide release / invalidate
-        __hip_atomic_store(o + 2 + d, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == 0) {
-          __hip_atomic_store(o, M4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(o + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      o[2 + d] = A;
+      if (d == 0) {
+        o[0] = M4;
+        o[1] = L;
       }
     }
-  }
-  if (counters == nullptr || nsplit == 1) return;   // partials are merged by attn_combine_kernel
-  // In-launch merge of the splits (cdna_hip_programming.md §5 "In-launch split-K reduction", write-through form): partials were
-  // stored with sc1 (agent-scope) stores; drain them, one relaxed agent-scope ticket per workgroup; the workgroup that draws the
-  // last ticket reads the row's nsplit partials with sc1 loads and merges them in split order (same arithmetic as
-  // attn_combine_kernel: the result does not depend on which workgroup is last).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* ticket_sm = reinterpret_cast<int*>(&sm[0][0]);
-  if (threadIdx.x == 0)
-    *ticket_sm = __hip_atomic_fetch_add(counters + (size_t)m * H + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (*ticket_sm != nsplit - 1) return;
-  if (threadIdx.x == 0) __hip_atomic_store(counters + (size_t)m * H + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (d < HD) {
-    const float* base = ws + ((size_t)m * H + h) * nsplit * (HD + 2);
-    auto ldc = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    float Mx = -INFINITY;
-    for (int sp = 0; sp < nsplit; ++sp) Mx = fmaxf(Mx, ldc(base + (size_t)sp * (HD + 2)));
-    const float mref = (Mx == -INFINITY) ? 0.f : Mx;
-    float L = 0.f, A = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float e = __expf(ldc(base + (size_t)sp * (HD + 2)) - mref);
-      L += ldc(base + (size_t)sp * (HD + 2) + 1) * e;
-      A += ldc(base + (size_t)sp * (HD + 2) + 2 + d) * e;
-    }
-    DT<T>::st(out + ((size_t)m * H + h) * HD + d, A / L);
   }
 }
 
@@ -930,7 +834,7 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                       const FusedQKV* fq, int* counters, const int32_t* row_pos, KvPages pages) {
+                       const int32_t* row_pos, KvPages pages) {
   const int M = Bp * Tq;
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
   // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
@@ -945,34 +849,23 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
   const float scale = 1.0f / sqrtf((float)HD);
   if (ev0) (void)hipEventRecord(ev0, st);
   if (pages.table != nullptr) {
-    if (fq != nullptr || pages.stride > 256) {
-      set_error("block-granular KV: fused-QKV attention is not available, and a row may hold at most 256 blocks (has %d)", pages.stride);
+    if (pages.stride > 256) {
+      set_error("block-granular KV: a row may hold at most 256 blocks (has %d)", pages.stride);
       return VLG_ERR_UNSUPPORTED;
     }
-    attn_partial_kernel<T, HD, VEC, LPR, false, 4, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale,
-                                                                                            FusedQKV{nullptr, 0, nullptr}, counters, row_pos, pages);
-  } else if (fq != nullptr && Tq == 1 && VEC % 2 == 0) {
-    if constexpr (VEC % 2 == 0)
-      attn_partial_kernel<T, HD, VEC, LPR, true, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                      Tc, scale, *fq, counters, row_pos);
+    attn_partial_kernel<T, HD, VEC, LPR, 4, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale,
+                                                                                     row_pos, pages);
   } else {
-    if (fq != nullptr) {
-      set_error("fused qkv attention needs Tq == 1");
-      return VLG_ERR_BAD_ARG;
-    }
     static const int u_knob = getenv("VLG_ATTN_U") ? atoi(getenv("VLG_ATTN_U")) : 4;
     if (u_knob == 8)
-      attn_partial_kernel<T, HD, VEC, LPR, false, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
     else if (u_knob == 2)
-      attn_partial_kernel<T, HD, VEC, LPR, false, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
     else
-      attn_partial_kernel<T, HD, VEC, LPR, false, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask,
-                                                                                         Tc, scale, FusedQKV{nullptr, 0, nullptr}, counters, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
-  if (nsplit > 1 && counters == nullptr) {
+  if (nsplit > 1) {
     if (nsplit <= 8)
       attn_combine_kernel<T, HD, 8><<<M * H, 64, 0, st>>>(ws, out, nsplit);
     else
@@ -984,11 +877,9 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
 template <typename T>
 int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
               int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-              const float* qkv_ws, int qkv_splits, const float* freqs, int* counters, const int32_t* row_pos, KvPages pages) {
-  FusedQKV fqv{qkv_ws, qkv_splits, freqs};
-  const FusedQKV* fq = qkv_ws ? &fqv : nullptr;
+              const int32_t* row_pos, KvPages pages) {
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, fq, counters, row_pos, pages)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, row_pos, pages)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -1006,8 +897,8 @@ int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* s
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*, KvPages);
-template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const float*, int, const float*, int*, const int32_t*, KvPages);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels

@@ -61,18 +61,21 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
     with torch.cuda.device(dev):
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"graph", C.c_int64(1 if model.use_graph else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"time_attn", C.c_int64(1 if model.time_attn else 0)))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"lanes", C.c_int64(int(model.lanes))))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_qkv", C.c_int64(1 if model.fuse_qkv else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_swiglu", C.c_int64(1 if model.fuse_swiglu else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_gemm", C.c_int64(1 if model.fuse_gemm else 0)))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"attn_inlaunch", C.c_int64(1 if model.attn_inlaunch else 0)))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"gemm_lds", C.c_int64(1 if getattr(model, "gemm_lds", False) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(1 if getattr(model, "dl_persist", True) else 0)))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_spin_max", C.c_int64(int(getattr(model, "debug_spin_max", 0)))))
         if latent and model._head_code() == L.VLG_HEAD_HIDDEN:
             L.check(L.lib().vlg_gpt_set_option_f64(model._handle, b"cfg_iter", C.c_double(float(cfg_iter))))
         L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
                                          C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
                                          L.stream_ptr(dev)))
+        # The C call returns with the work enqueued (include/vlg.h).  The persistent kernels bound their in-launch waits and report a
+        # wait that ran out through the handle's fault word: by default the mirror waits for the call and raises VlgError instead of
+        # handing out the poisoned results; model.check_faults = False keeps the call asynchronous (the fault then surfaces on the
+        # next call, or through model.status()).
+        if getattr(model, "check_faults", True):
+            L.check(L.lib().vlg_gpt_status(model._handle, C.c_int32(1)))
     return (out_lat if latent else out_ids), trace_d
 
 

@@ -112,11 +112,9 @@ class Transformer:
         self.time_attn = False
         self.fuse_gemm = True    # decode: fused skinny GEMMs (norm prologue, residual / RoPE+scatter / SwiGLU epilogues)
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
-        self.attn_inlaunch = False  # split-KV partials merged inside the attention launch (slower on MI355X, see gpt.hip)
-        self.fuse_qkv = False    # decode: RoPE + KV append fused into the attention kernel
+        self.check_faults = True  # generate(): wait for the call and raise on a device-side time-out (False: asynchronous, see status())
+        self.debug_spin_max = 0   # tests: spin bound of the persistent kernels' in-launch waits (0 = default)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
-        self.gemm_lds = False    # decode GEMMs on the LDS-DMA kernel with row statistics handed between kernels (see csrc/gemm_fused.hip)
-        self.lanes = 0          # 0 = auto: independent batch lanes on forked graph branches (see csrc/gpt.hip)
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
     def eval(self):
@@ -262,6 +260,11 @@ class Transformer:
         ms, by, n = C.c_double(), C.c_double(), C.c_int64()
         L.check(L.lib().vlg_gpt_attn_timing(self._handle, C.byref(ms), C.byref(by), C.byref(n)))
         return ms.value, by.value, n.value
+
+    def status(self, sync=True):
+        """Raises VlgError(VLG_ERR_STATE) if a persistent kernel of this handle recorded a time-out since the last check."""
+        if self._handle is not None:
+            L.check(L.lib().vlg_gpt_status(self._handle, C.c_int32(1 if sync else 0)))
 
     def graphs_built(self):
         """decode-step graphs instantiated by this handle so far (a repeated generate() of the same shape must not add one)."""

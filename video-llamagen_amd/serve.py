@@ -268,12 +268,13 @@ class ContinuousLLMEngine:
                 return []
             self._begin(self.waiting[0].params)
         row_class = (C.c_int32 * self.slots_n)()
-        for i, s in enumerate(self.slots):
+        blocked = False                                             # the head of the queue waits for KV blocks: nobody overtakes it (FIFO),
+        for i, s in enumerate(self.slots):                          # but every later slot still gets its own code (-1 running, -2 idle)
             if s is not None:
                 row_class[i] = -1                                   # continue
                 continue
             row_class[i] = -2                                       # idle unless a waiting request fits
-            if self.waiting:
+            if self.waiting and not blocked:
                 r = self.waiting[0]
                 if r.params.max_tokens > self.session_tokens:
                     raise ValueError("request %s asks for %d tokens, the session holds %d" % (r.request_id, r.params.max_tokens, self.session_tokens))
@@ -282,7 +283,8 @@ class ContinuousLLMEngine:
                 if not self._reserve(i, r):
                     if not any(self.slots):
                         raise ValueError("request %s does not fit the KV pool even when it is empty" % r.request_id)
-                    break                                           # FIFO: wait for blocks instead of overtaking
+                    blocked = True                                  # FIFO: wait for blocks instead of overtaking
+                    continue
                 if self.text:
                     self.waiting.popleft()
                     dev = self.model._device
