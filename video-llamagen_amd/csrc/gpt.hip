@@ -23,11 +23,12 @@ struct Lane {
   DevBuf kcache, vcache, ws, attn_ws, x, xn, q, ao, g, t1, condT, hl, latT, y, logits, state, cur_tok, cur_lat;
   DevBuf d_cemb, d_ys, d_mod, d_h, d_g, d_g1, d_out, d_x, d_x2;   // DiffLoss head (d_ys / d_mod hold all S steps on the fused path)
   DevBuf dp_xbuf;                                           // persistent DiffLoss sampler: exchange buffer
+  DevBuf pd_xbuf;                                           // persistent decode step: hand-off granules (zeroed when a generate() call starts)
   DevBuf maskbuf;                                           // this lane's rows of the caller's emb_mask (stable address for the cached graph)
   std::vector<uint64_t> ptr_key() const {                   // every address a captured decode step can hold
     std::vector<uint64_t> k;
     for (const DevBuf* b : {&kcache, &vcache, &ws, &attn_ws, &x, &xn, &q, &ao, &g, &t1, &condT, &hl, &latT, &y, &logits, &state, &cur_tok,
-                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &maskbuf, &dp_xbuf})
+                            &cur_lat, &d_cemb, &d_ys, &d_mod, &d_h, &d_g, &d_g1, &d_out, &d_x, &d_x2, &maskbuf, &dp_xbuf, &pd_xbuf})
       k.push_back((uint64_t)(uintptr_t)b->p);
     return k;
   }
@@ -65,6 +66,8 @@ struct vlg_gpt {
   unsigned* fault_host = nullptr;    // pinned, device-visible fault word(s) of the persistent kernels (vlg_gpt_status)
   unsigned* fault_dev = nullptr;
   int spin_max = 0;                  // option debug_spin_max (0 = default bound)
+  bool pdecode = true;               // decode layers as one persistent launch per step (pdecode.hip) where the shape allows
+  DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
@@ -400,6 +403,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->spin_max = (int)value;
     return VLG_OK;
   }
+  if (!strcmp(key, "pdecode")) {
+    h->pdecode = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "dl_persist")) {
     h->dl_persist_on = value != 0;
     return VLG_OK;
@@ -449,6 +456,21 @@ extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* 
 }
 
 namespace {
+
+// PdLayer[L] for the persistent decode kernel: weight buffers are allocated at create, so the pointers never change (built outside of
+// any stream capture)
+int ensure_pd_layers(vlg_gpt* h) {
+  if (h->pd_layers_dev.p != nullptr) return VLG_OK;
+  std::vector<PdLayer> v(h->L);
+  for (int l = 0; l < h->L; ++l) {
+    const std::string p = "layers." + std::to_string(l) + ".";
+    v[l] = PdLayer{h->W(p + "attention.wqkv.weight"), h->W(p + "attention.wo.weight"), h->W(p + "feed_forward.w13"),
+                   h->W(p + "feed_forward.w2.weight"), h->W(p + "attention_norm.weight"), h->W(p + "ffn_norm.weight")};
+  }
+  VLG_TRY(h->pd_layers_dev.reserve(v.size() * sizeof(PdLayer)));
+  VLG_HIP(hipMemcpy(h->pd_layers_dev.p, v.data(), v.size() * sizeof(PdLayer), hipMemcpyHostToDevice));
+  return VLG_OK;
+}
 
 // A Runner drives one set of buffers (Lane: activations, KV cache, step state, stream) through prefill / decode steps.  b0 / Btot
 // place its rows inside a larger call (sessions prefill one slot at a time).  Splitting a batch into concurrent lanes on forked graph
@@ -586,6 +608,35 @@ struct Runner {
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
     }
     return VLG_OK;
+  }
+
+  // ---- persistent decode step: all layers in one launch (pdecode.hip) -------------------------------------------------------
+  bool pd_use() {
+    static const int off = getenv("VLG_PDECODE") ? (atoi(getenv("VLG_PDECODE")) == 0) : 0;
+    static const int rows_max = getenv("VLG_PD_ROWS") ? atoi(getenv("VLG_PD_ROWS")) : 16;
+    if (off || !h->pdecode || row_pos != nullptr || pages.table != nullptr || kv_rows != 0 || ev_slot >= 0 || Bp > rows_max) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return ln->pd_xbuf.p != nullptr && h->pd_layers_dev.p != nullptr && pd_ok<T>(Bp, h->D, h->H, h->hd, h->F, S, cus);
+  }
+  int layers_pd() {
+    PdArgs a{};
+    a.layers = h->pd_layers_dev.as<PdLayer>();
+    a.x = ln->x.p;
+    a.kc = ln->kcache.p;
+    a.vc = ln->vcache.p;
+    a.kv_lstride = kv_lstride();
+    a.freqs = h->freqs.as<float>();
+    a.state = state();
+    a.mask = mask;
+    a.Bmask = B;
+    a.Tc = h->Tc;
+    a.xbuf = ln->pd_xbuf.p;
+    a.fault = h->fault_dev;
+    a.spin_max = h->spin_max;
+    a.L = h->L; a.M = Bp; a.D = h->D; a.H = h->H; a.hd = h->hd; a.F = h->F; a.S = S;
+    a.eps = h->cfg.norm_eps;
+    return pd_layers<T>(a, st);
   }
 
   // head on the un-normed residual stream x [Bp, D]: the final RMSNorm (gpt.py:370) is the head GEMM's prologue
@@ -846,7 +897,10 @@ struct Runner {
       VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st));
     }
     if (fused_decode_ok()) {
-      VLG_TRY(layers_fused());
+      if (pd_use())
+        VLG_TRY(layers_pd());
+      else
+        VLG_TRY(layers_fused());
       VLG_TRY(head_fused(sp, noise, out_ids, out_lat, trace));
     } else {
       VLG_TRY(layers(1, S - 1));
@@ -949,6 +1003,7 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
   VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
   VLG_TRY(ln.state.reserve(sizeof(StepState)));
+  if (Bp <= 32 && pool_blocks == 0) VLG_TRY(ln.pd_xbuf.reserve(pd_xbuf_bytes(Bp, D, H, hd, F, (int)e)));
   if (!ln.st) VLG_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
   if (!ln.ev) VLG_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
   return VLG_OK;
@@ -976,6 +1031,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     out_ids = h->outbuf.as<int32_t>();
   Lane* ln = &h->lane;
   VLG_TRY(reserve_lane(h, *ln, B, cfg_on ? 2 * B : B, S));
+  VLG_TRY(ensure_pd_layers(h));
   if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)B * Tc * sizeof(float)));
   Runner<T> r{h, ln, ln->st, B, cfg_on ? 2 * B : B, N, S, 0, B, d_mask ? ln->maskbuf.as<float>() : nullptr};
   if (h->cfg.head == VLG_HEAD_HIDDEN) {
@@ -987,6 +1043,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   VLG_HIP(hipEventRecord(h->ev_in, caller));
   VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
   if (d_mask) VLG_HIP(hipMemcpyAsync(ln->maskbuf.p, d_mask, (size_t)B * Tc * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  if (ln->pd_xbuf.p) VLG_HIP(hipMemsetAsync(ln->pd_xbuf.p, 0, ln->pd_xbuf.bytes, r.st));   // hand-off tags count up from the call's first step
   VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   hipStream_t s0 = r.st;
   const int steps = N - 1;
@@ -1040,7 +1097,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(int64_t)sp.cfg_interval, fbits(sp.temperature), (uint64_t)(int64_t)sp.top_k, fbits(sp.top_p),
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
-                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
+                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
                                    (uint64_t)h->spin_max};
       {

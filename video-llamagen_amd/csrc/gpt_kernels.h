@@ -209,6 +209,67 @@ bool dl_persist_ok(int B, int W, int C, int depth);
 template <typename T>
 int dl_persist(const DlPersist& p, hipStream_t st);
 
+// ---- persistent decode step (pdecode.hip): the L transformer layers of one decode step (Tq = 1) in ONE launch -----------------------
+struct PdLayer {   // device array [L]: one layer's weights (handle dtype), as nn.Linear stores them
+  const void* wqkv;   // [3D, D]
+  const void* wo;     // [D, D]
+  const void* w13;    // [2F, D]  (w1 rows, then w3 rows)
+  const void* w2;     // [D, F]
+  const void* norm1;  // attention_norm.weight [D]
+  const void* norm2;  // ffn_norm.weight [D]
+};
+struct PdArgs {
+  const PdLayer* layers;
+  void* x;                 // [M][D] residual stream: layer 0's input on entry, the last layer's output on exit (not normed)
+  void* kc;                // KV cache [L][M][H][S][hd] (contiguous form), layer stride kv_lstride elements
+  void* vc;
+  size_t kv_lstride;
+  const float* freqs;      // RoPE table
+  const StepState* state;  // uniform position of the step
+  const float* mask;       // [Bmask][Tc] or null
+  int Bmask, Tc;
+  void* xbuf;              // exchange granules {4 payload bytes, epoch tag}, PdXbuf layout; zero at allocation, tags only grow
+  unsigned xbuf_bytes;
+  unsigned* epoch;         // device word: tag base of this launch, advanced by the kernel (so a replayed graph never repeats a tag)
+  unsigned* fault;         // host-visible fault word of the handle
+  int spin_max;
+  int L, M, D, H, hd, F, S;
+  float eps;
+  int kchunk;              // K elements of the w2 GEMM staged in LDS at a time (a multiple of 8 k-steps)
+  int ns_max;              // upper bound of the attention KV splits
+  int ksplit;              // K slices of a wo / w2 output tile (units = D / 16 * ksplit <= workgroups)
+#ifdef VLG_PD_PROF
+  unsigned long long* prof;   // tools/microbench/pd_lab.hip only: [workgroups][32] wall_clock64 stamps of layer 1
+#endif
+};
+// granule offsets (8-byte units) of the exchange regions, both parities; shared by host and device
+struct PdXbuf {
+  unsigned nx, nq, ng, nap, nwp, per_parity;
+  __host__ __device__ PdXbuf(int M, int D, int F, int H, int hd, int esz, int ns_max, int ksplit) {
+    nx = (unsigned)M * D * esz / 4;
+    nq = 3 * nx;
+    ng = (unsigned)M * F * esz / 4;
+    nap = (unsigned)M * H * ns_max * (hd + 2);
+    nwp = (unsigned)(D / 16) * ksplit * (M > 16 ? 2 : 1) * 256;
+    per_parity = 3 * nx + nq + ng + nap + 2 * nwp;
+  }
+  __host__ __device__ unsigned X(int par) const { return par * per_parity; }            // layer input rows (w2 output of the layer before)
+  __host__ __device__ unsigned Q(int par) const { return X(par) + nx; }                 // q | k | v rows of the current position, RoPE applied
+  __host__ __device__ unsigned AO(int par) const { return Q(par) + nq; }                // attention output rows
+  __host__ __device__ unsigned HH(int par) const { return AO(par) + nx; }               // residual stream after attention
+  __host__ __device__ unsigned G(int par) const { return HH(par) + nx; }                // SwiGLU output rows
+  __host__ __device__ unsigned AP(int par) const { return G(par) + ng; }                // attention partials of the non-owner KV splits (fp32)
+  __host__ __device__ unsigned WP(int par) const { return AP(par) + nap; }              // wo tile partials of the non-owner K slices (fp32) [tile][slice][mt][256]
+  __host__ __device__ unsigned W2P(int par) const { return WP(par) + nwp; }             // w2 tile partials
+  __host__ __device__ size_t bytes() const { return (size_t)2 * per_parity * 8; }
+};
+// can this shape run on the persistent kernel (otherwise: the launch chain of layers_fused)?  cus = compute units of the device
+template <typename T>
+bool pd_ok(int M, int D, int H, int hd, int F, int S, int cus);
+size_t pd_xbuf_bytes(int M, int D, int H, int hd, int F, int esz);
+template <typename T>
+int pd_layers(PdArgs a, hipStream_t st);
+
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
 template <typename T>

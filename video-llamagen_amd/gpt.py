@@ -114,6 +114,7 @@ class Transformer:
         self.fuse_swiglu = True  # w1/w3 GEMM with the SiLU*mul epilogue
         self.check_faults = True  # generate(): wait for the call and raise on a device-side time-out (False: asynchronous, see status())
         self.debug_spin_max = 0   # tests: spin bound of the persistent kernels' in-launch waits (0 = default)
+        self.pdecode = True      # decode: all layers of a step as one persistent launch (csrc/pdecode.hip) where the shape allows (<= 16 rows)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
