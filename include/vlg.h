@@ -137,7 +137,7 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "dl_persist" (1: DiffLoss sampler as one persistent launch per
- * token), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
+ * token), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
  * of rounds 1-2 - batch lanes, fuse_qkv, attn_inlaunch, splitk_inlaunch, gemm_lds - were removed in round 3; DESIGN.md section 5
  * keeps their measurements.)                                                                                         */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
@@ -158,6 +158,10 @@ int vlg_gpt_status(vlg_gpt_t* h, int32_t sync);
 /* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last
  * call and replays it while shape, sampling parameters, options and buffer addresses are unchanged                           */
 int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count);
+/* host-side counters of this handle (tests prove which decode path a call took): "pd_steps" = decode steps recorded (launched eagerly or
+ * captured into a graph) as ONE persistent launch over all layers (csrc/pdecode.hip; option "pdecode", default 1, small row counts);
+ * "chain_steps" = decode steps recorded as the per-layer launch chain; "graphs_built".  Unknown keys return VLG_ERR_BAD_ARG.        */
+int vlg_gpt_counter(vlg_gpt_t* h, const char* key, int64_t* count);
 /* event-timed attention launches of the last generate() with time_attn=1: total ms, total algorithmic KV bytes
  * (2 * Bp * D * (p+1) * elem per launch), number of launches                                                      */
 int vlg_gpt_attn_timing(vlg_gpt_t* h, double* ms_sum, double* bytes_sum, int64_t* launches);

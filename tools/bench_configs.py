@@ -2,6 +2,7 @@
 """Secondary configurations of BASELINE.json / SURVEY.md §8d on one MI355X (random-init weights, synthetic conditions):
   serve-readme : the reference's only published workload (autoregressive/serve/README.md:12-16): c2i 384x384 (576 tokens),
                  8 classes, cfg 4.0, top-k 2000, bf16, for GPT-B/L/XL/XXL/3B  -> sampling wall time (+ VQ decode time)
+  c2           : GPT-L c2i 384x384 (576 tokens), 8 classes, cfg 4.0 (16 rows), top-k 2000
   c3           : GPT-XL t2i 512x512 (1024 tokens), 120 text tokens, cfg 7.5, top-k 1000, B = 4
   c5           : GPT-3B c2i 384x384, B = 32 per GPU, cfg 1.65 (B' = 64, head_dim 100)
 Prints one JSON line per configuration."""
@@ -53,6 +54,10 @@ def main():
             r.update(config="serve-readme", ref_a100_pytorch_s=ref[name][0], ref_a100_vllm_s=ref[name][1],
                      speedup_vs_a100_pytorch=ref[name][0] / r["sampling_s"], speedup_vs_a100_vllm=ref[name][1] / r["sampling_s"])
             print(json.dumps(r), flush=True)
+    if "c2" in which:   # BASELINE config 2: GPT-L c2i 384 px, 8 classes, cfg 4.0 (16 rows), top-k 2000
+        r = c2i("GPT-L", 8, 24, 4.0, 2000, vq)
+        r["config"] = "c2"
+        print(json.dumps(r), flush=True)
     if "c3" in which:
         m = V.GPT_models["GPT-XL"](block_size=1024, cls_token_num=120, model_type="t2i").to(dev, torch.bfloat16).init_random_weights(seed=1)
         cond, mask = synthetic_text(4, 120, 2048, 1, dev)

@@ -67,6 +67,7 @@ struct vlg_gpt {
   unsigned* fault_dev = nullptr;
   int spin_max = 0;                  // option debug_spin_max (0 = default bound)
   bool pdecode = true;               // decode layers as one persistent launch per step (pdecode.hip) where the shape allows
+  int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured default, pd_rows_default())
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
@@ -97,6 +98,7 @@ struct vlg_gpt {
   } gc;
   DevBuf outbuf;                     // [B, N] int32 ids or [B, N, C] fp32 latents of the running call
   long long graphs_built = 0;        // instantiations so far (tests: a repeated call must not add one)
+  long long pd_steps = 0, chain_steps = 0;   // decode steps recorded on the persistent / the per-layer path (vlg_gpt_counter)
   bool fuse_gemm = true;             // decode: fused skinny GEMMs (RMSNorm prologue; residual / RoPE+scatter / SwiGLU epilogues)
   bool fuse_swiglu = true;           // w1/w3 GEMM with the SiLU*mul epilogue
   bool time_attn = false;            // eager decode loop with HIP events around layer 0's split-KV attention kernel
@@ -407,6 +409,11 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->pdecode = value != 0;
     return VLG_OK;
   }
+  if (!strcmp(key, "pd_rows")) {
+    VLG_CHECK(value >= 0 && value <= 32, VLG_ERR_BAD_ARG, "pd_rows must be in 0..32");
+    h->pd_rows = (int)value;
+    return VLG_OK;
+  }
   if (!strcmp(key, "dl_persist")) {
     h->dl_persist_on = value != 0;
     return VLG_OK;
@@ -430,6 +437,18 @@ static int collect_fault(vlg_gpt* h) {
 extern "C" int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count) {
   VLG_CHECK(h && count, VLG_ERR_BAD_ARG, "vlg_gpt_graphs_built: null argument");
   *count = h->graphs_built;
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_counter(vlg_gpt_t* h, const char* key, int64_t* count) {
+  VLG_CHECK(h && key && count, VLG_ERR_BAD_ARG, "vlg_gpt_counter: null argument");
+  if (!strcmp(key, "pd_steps")) *count = h->pd_steps;
+  else if (!strcmp(key, "chain_steps")) *count = h->chain_steps;
+  else if (!strcmp(key, "graphs_built")) *count = h->graphs_built;
+  else {
+    set_error("vlg_gpt_counter: unknown key %s", key);
+    return VLG_ERR_BAD_ARG;
+  }
   return VLG_OK;
 }
 
@@ -613,10 +632,15 @@ struct Runner {
   // ---- persistent decode step: all layers in one launch (pdecode.hip) -------------------------------------------------------
   bool pd_use() {
     static const int off = getenv("VLG_PDECODE") ? (atoi(getenv("VLG_PDECODE")) == 0) : 0;
-    static const int rows_max = getenv("VLG_PD_ROWS") ? atoi(getenv("VLG_PD_ROWS")) : 16;
-    if (off || !h->pdecode || row_pos != nullptr || pages.table != nullptr || kv_rows != 0 || ev_slot >= 0 || Bp > rows_max) return false;
+    // Measured against the launch chain: faster up to 8 rows; up to 16 rows while the (row, head) attention items fit
+    // one round of the grid (GPT-B / GPT-L under guidance: 8 classes = 16 rows x 16 heads = 256 items); slower beyond.  Option "pd_rows" /
+    // VLG_PD_ROWS replace the rule by a plain row cap.
+    static const int rows_env = getenv("VLG_PD_ROWS") ? atoi(getenv("VLG_PD_ROWS")) : 0;
+    const int rows_cap = h->pd_rows > 0 ? h->pd_rows : rows_env;
+    if (off || !h->pdecode || row_pos != nullptr || pages.table != nullptr || kv_rows != 0 || ev_slot >= 0) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (rows_cap > 0 ? Bp > rows_cap : !(Bp <= 8 || (Bp <= 16 && Bp * h->H <= cus))) return false;
     return ln->pd_xbuf.p != nullptr && h->pd_layers_dev.p != nullptr && pd_ok<T>(Bp, h->D, h->H, h->hd, h->F, S, cus);
   }
   int layers_pd() {
@@ -897,10 +921,13 @@ struct Runner {
       VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st));
     }
     if (fused_decode_ok()) {
-      if (pd_use())
+      if (pd_use()) {
         VLG_TRY(layers_pd());
-      else
+        h->pd_steps += 1;
+      } else {
         VLG_TRY(layers_fused());
+        h->chain_steps += 1;
+      }
       VLG_TRY(head_fused(sp, noise, out_ids, out_lat, trace));
     } else {
       VLG_TRY(layers(1, S - 1));
@@ -1099,7 +1126,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
-                                   (uint64_t)h->spin_max};
+                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows};
       {
         const auto pk = ln->ptr_key();
         key.insert(key.end(), pk.begin(), pk.end());

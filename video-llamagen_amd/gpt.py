@@ -115,6 +115,7 @@ class Transformer:
         self.check_faults = True  # generate(): wait for the call and raise on a device-side time-out (False: asynchronous, see status())
         self.debug_spin_max = 0   # tests: spin bound of the persistent kernels' in-launch waits (0 = default)
         self.pdecode = True      # decode: all layers of a step as one persistent launch (csrc/pdecode.hip) where the shape allows (<= 16 rows)
+        self.pd_rows = 0         # ... up to this many cache rows (0 = the library's measured default)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
@@ -271,6 +272,12 @@ class Transformer:
         """decode-step graphs instantiated by this handle so far (a repeated generate() of the same shape must not add one)."""
         n = C.c_int64()
         L.check(L.lib().vlg_gpt_graphs_built(self._handle, C.byref(n)))
+        return n.value
+
+    def counter(self, key):
+        """host-side counters of the handle: "pd_steps" / "chain_steps" (decode steps recorded on the persistent / per-layer path), "graphs_built"."""
+        n = C.c_int64()
+        L.check(L.lib().vlg_gpt_counter(self._handle, key.encode(), C.byref(n)))
         return n.value
 
     def attn_event_overhead_ms(self):
