@@ -54,7 +54,18 @@ def build_gpt(V, a, device, head=None):
                                   caption_dim=2048, head=head or a.head)
     m.to(device=device, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).eval()
     m.init_random_weights(seed=1234)
+    if os.environ.get("VLG_BENCH_ONE_DEVICE"):
+        # Rehearsal: several ranks share ONE card.  The persistent kernels (decode step, DiffLoss sampler) need their whole grid resident and
+        # two of them from two processes can split the compute units between them - each then waits for workgroups that cannot start, the
+        # bounded waits run out and the call fails with VLG_ERR_STATE (observed; include/vlg.h "Device-side faults").  One process per GPU,
+        # as the driver launches it, never shares a card.
+        m.pdecode = False
+        m.dl_persist = False
     return m
+
+
+# one-GPU timings of the per-GPU shards of the 32-video job (bench.py --batch b --no-vae, + b/4 VAE decode calls of 0.11 s), DESIGN.md section 6
+PROJECTED_STRONG = {"basis_s_per_step": {"32": 20.8, "16": 13.4, "8": 9.3, "4": 6.9}, "speedup": {"2": 1.55, "4": 2.2, "8": 3.0}}
 
 
 def synth_cond(B, device, seed):
@@ -71,6 +82,7 @@ def cpu_baseline(a):
     """The numpy oracle (a port, not the reference) on the host cores, on a bounded sample of the same workload: GPT-XL t2v fp32,
     same shapes, batch 2, prefill + 5 decode steps; then one latent frame of the CausalVideoVAE decoder at full width (about 10 s in all)."""
     import threadpoolctl  # noqa: F401  (numpy BLAS thread count is reported)
+    threadpoolctl.threadpool_limits(limits=16)   # a one-GPU box's share of the host (more BLAS threads than that oversubscribe it: 2x slower)
     from oracle import cases, detweights
     from oracle import vlg_oracle as O
     cb, nsteps = 2, 6
@@ -104,6 +116,15 @@ def cpu_baseline(a):
     res["vae"] = {"value": 0.0625 / dv, "unit": "256x256-frame equivalents/s", "sample":
                   f"numpy oracle, CausalVideoVAE decoder (constructor defaults, fp32), 1 latent frame 8x8 -> {tuple(y.shape)} in {dv:.1f}s "
                   f"(0.09 TFLOP; a 17-frame 256x256 video is 19.95 TFLOP)"}
+    # BASELINE config 1 exactly as BASELINE.md section 3 planned it: LlamaGen-B c2i 256x256 (256 tokens), one class, greedy, fp32, batch 1
+    # (the reference's own CPU-runnable case; the same call tests/test_oracle_golden.py pins to the reference's ids)
+    b_sd = detweights.gpt_weights(cases.GPT_B)
+    bm = O.GPTOracle(cases.GPT_B, b_sd, "fp32")
+    t0 = time.time()
+    ids = O.generate(bm, np.array([207]), 256, None, cfg_scale=1.0, cfg_interval=-1, sample_logits=False)
+    d1 = time.time() - t0
+    res["config1"] = {"value": 256 / d1, "unit": "image tokens/s", "sample": f"numpy oracle, GPT-B c2i 16x16 tokens, class 207, greedy, fp32, batch 1: "
+                      f"{ids.shape[1]} tokens in {d1:.1f}s"}
     return res
 
 
@@ -341,8 +362,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    last = None
     for i in range(a.steps):
-        step()
+        last = step()
         if rank == 0:
             log(f"[bench] step {i + 1}/{a.steps} enqueued at {elapsed():.0f} s")
     torch.cuda.synchronize()
@@ -369,6 +391,14 @@ def main():
         "frames_per_s": (global_batch * a.num_frames * a.steps / dt) if vae is not None else None,
         "tokens_per_s_per_gpu": tokens / dt / world,
     }
+    if world > 1:
+        # what rank 0 holds after the step's all_gather (ragged shards padded to the largest one), and what one GPU's shard timings project
+        # for this strong-scaling run (measured on ONE GPU with --batch 32/N --no-vae, the VAE share added; the driver
+        # computes the real efficiency from the per-N lines)
+        res["gathered_shape"] = list(last.shape) if last is not None else None
+        res["config"]["shard_sizes"] = [shard_range(a.batch, r, world)[1] - shard_range(a.batch, r, world)[0] for r in range(world)] \
+            if scaling == "strong" else [B] * world
+        res["config"]["projected_strong_speedup_from_one_gpu_shards"] = PROJECTED_STRONG
 
     if rank == 0 and not a.no_roofline:
         if not roof_done:           # --warmup 0: one extra instrumented step after the timed region
@@ -424,6 +454,22 @@ def main():
                 extras["C4_diffloss_head"] = {"workload": f"{a.gpt_model} t2v, hidden head + DiffLoss sampler (100 DDPM steps per token, gpt_video_diff.py), "
                                                           f"{B} videos, first {nh} of 5120 latent tokens (positions 120..{119 + nh}), bf16, sampling only",
                                               "sampling_s": dth, "tokens_per_s": B * nh / dth, "ms_per_token_step": 1e3 * dth / nh}
+                if elapsed() + 6 <= a.budget_s:
+                    # the same head at LATE context: positions 4984..5239 (the last 256 of the 5120 latent tokens) over a zero-filled cache
+                    # prefix (handle option debug_pos_offset) - what a token step costs where attention reads the whole context
+                    off = a.latent ** 2 * ((a.num_frames - 1) // 4 + 1) - nh
+                    gh.debug_pos_offset = off
+                    V.generate_t2v(gh, cond, 2, mask)            # allocation of the full-length cache outside the timed call
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    V.generate_t2v(gh, cond, nh, mask)
+                    torch.cuda.synchronize()
+                    dtl = time.perf_counter() - t
+                    extras["C4_diffloss_head_late"] = {"workload": f"as C4_diffloss_head, last {nh} of the 5120 latent tokens (positions {120 + off}..{119 + off + nh}; "
+                                                                   "earlier cache rows zero-filled)",
+                                                       "sampling_s": dtl, "tokens_per_s": B * nh / dtl, "ms_per_token_step": 1e3 * dtl / nh}
+                else:
+                    skipped.append("C4_diffloss_head_late")
                 del gh
             else:
                 skipped.append("C4_diffloss_head")

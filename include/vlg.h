@@ -137,7 +137,9 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "dl_persist" (1: DiffLoss sampler as one persistent launch per
- * token), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
+ * token), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts; "pd_rows" = row
+ * cap replacing the measured rule), "debug_pos_offset" (0; benchmarks: decode starts `offset` positions after the condition, over zeroed
+ * cache rows - the cost of a late-context step without generating up to it), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
  * of rounds 1-2 - batch lanes, fuse_qkv, attn_inlaunch, splitk_inlaunch, gemm_lds - were removed in round 3; DESIGN.md section 5
  * keeps their measurements.)                                                                                         */
 int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
@@ -153,7 +155,12 @@ int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value);
  * fault's kernel / phase in vlg_last_error().  sync != 0 first waits for the handle's stream (vlg_gpt_generate itself returns with the
  * work enqueued); vlg_gpt_generate and the session calls also return VLG_ERR_STATE on entry while an uncollected fault is pending.
  * Option "debug_spin_max" (default 0 = the built-in bound of ~1 s): spin bound of every in-launch wait; 1 makes the first wait that is
- * not satisfied at once give up - how the tests inject a time-out without oversubscribing the chip.                              */
+ * not satisfied at once give up - how the tests inject a time-out without oversubscribing the chip.
+ * EXCLUSIVITY: a persistent launch wants one workgroup on every compute unit of the device.  One process per GPU with one generate() in
+ * flight (the deployment this library is built for) always satisfies that.  Two PROCESSES that share one GPU and both run persistent
+ * launches can split the compute units between them; both then time out (observed with two benchmark ranks on one card: VLG_ERR_STATE on
+ * the first decode step, never wrong results).  When a GPU is shared, set options "pdecode" = 0 and "dl_persist" = 0: the per-layer launch
+ * chains need no residency.                                                                                                        */
 int vlg_gpt_status(vlg_gpt_t* h, int32_t sync);
 /* number of decode-step graphs this handle has instantiated so far: vlg_gpt_generate keeps the instantiated graph of its last
  * call and replays it while shape, sampling parameters, options and buffer addresses are unchanged                           */

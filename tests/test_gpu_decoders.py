@@ -271,6 +271,14 @@ def test_vae_from_pretrained_dir(tmp_path):
     m = V.CausalVAEModel.from_pretrained(str(d), device="cuda", dtype=torch.float32)
     z = torch.from_numpy(cases.rng(31).standard_normal((1, cfg["embed_dim"], 3, 4, 4), dtype=np.float32))
     assert torch.equal(m.decode(z), _vae(torch.float32).decode(z))
+    # the diffusers layout (no *.ckpt: modeling_videobase.py:52-53 -> ModelMixin.from_pretrained): config.json + safetensors
+    from safetensors.torch import save_file
+    d2 = tmp_path / "vae_hub"
+    d2.mkdir()
+    (d2 / "config.json").write_text((d / "config.json").read_text())
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d2 / "diffusion_pytorch_model.safetensors"))
+    m2 = V.CausalVAEModel.from_pretrained(str(d2), device="cuda", torch_dtype=torch.float32)
+    assert torch.equal(m2.decode(z), m.decode(z))
 
 
 def test_vae_full_size_batch_invariance():

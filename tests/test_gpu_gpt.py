@@ -759,3 +759,25 @@ def test_persistent_decode_step_timeout_is_an_error():
     assert ei.value.code == _lib.VLG_ERR_STATE and "persistent decode step" in str(ei.value)
     m.debug_spin_max = 0
     assert torch.equal(V.generate(m, cond, cfg["block_size"], cfg_scale=2.5, sample_logits=False), good)
+
+
+def test_debug_pos_offset_decodes_late_context():
+    """Option debug_pos_offset (bench.py's late-context timing of the DiffLoss head): decode starts `offset` positions after the condition
+    over ZERO cache rows.  Checked against the oracle run the same way is not possible (the reference has no such mode); properties: the
+    first latent (prefill output) does not depend on the offset, later ones do (they attend to the zero rows), everything is finite, the
+    RoPE-table bound is enforced, and offset 0 afterwards restores the plain result bit for bit."""
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib
+    cfg = cases.TINY_T2V
+    m, _ = product_gpt(cfg, torch.float32)
+    c, mk = cases.text_cond(2, cfg["cls_token_num"], cfg["caption_dim"])
+    c, mk = torch.from_numpy(c), torch.from_numpy(mk)
+    base = V.generate_t2v(m, c, 6, mk)
+    m.debug_pos_offset = 5
+    late = V.generate_t2v(m, c, 6, mk)
+    assert torch.isfinite(late).all() and torch.equal(late[:, 0], base[:, 0]) and not torch.equal(late[:, 1:], base[:, 1:])
+    m.debug_pos_offset = 4000
+    with pytest.raises(_lib.VlgError):
+        V.generate_t2v(m, c, 6, mk)
+    m.debug_pos_offset = 0
+    assert torch.equal(V.generate_t2v(m, c, 6, mk), base)

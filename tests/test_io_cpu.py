@@ -51,6 +51,34 @@ def test_find_vae_checkpoint(tmp_path):
     assert ck == glob.glob(os.path.join(str(d), "*.ckpt"))[-1]
 
 
+def test_find_vae_checkpoint_diffusers_layout(tmp_path):
+    """modeling_videobase.py:52-53: without a *.ckpt the directory is read the way diffusers' ModelMixin.from_pretrained does -
+    diffusion_pytorch_model[.variant].safetensors first, then .bin, optionally under a subfolder; tensors round-trip bit for bit."""
+    from safetensors.torch import save_file
+    d = tmp_path / "hub"
+    (d / "vae").mkdir(parents=True)
+    cfgj = json.dumps({"_class_name": "CausalVAEModel", "_diffusers_version": "0.24.0", "hidden_size": 32, "embed_dim": 8})
+    (d / "config.json").write_text(cfgj)
+    (d / "vae" / "config.json").write_text(cfgj)
+    with pytest.raises(FileNotFoundError):
+        vio.find_vae_checkpoint(str(d))
+    sd = {"decoder.conv_in.conv.weight": torch.randn(4, 3, 3, 3, 3), "decoder.conv_in.conv.bias": torch.randn(4).to(torch.bfloat16)}
+    torch.save(sd, str(d / "diffusion_pytorch_model.bin"))
+    cfg, path = vio.find_vae_checkpoint(str(d))
+    assert cfg == {"hidden_size": 32, "embed_dim": 8} and path.endswith("diffusion_pytorch_model.bin")
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    save_file(sd, str(d / "vae" / "diffusion_pytorch_model.fp16.safetensors"))
+    cfg, path = vio.find_vae_checkpoint(str(d))
+    assert path.endswith("diffusion_pytorch_model.safetensors")           # safetensors preferred over .bin
+    got = vio.load_vae_weight_file(path)
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) and got[k].dtype == sd[k].dtype for k in sd)
+    assert vio.select_vae_state_dict(got).keys() == sd.keys()              # a plain state dict passes through unchanged
+    cfg, path = vio.find_vae_checkpoint(str(d), subfolder="vae", variant="fp16")
+    assert path == os.path.join(str(d), "vae", "diffusion_pytorch_model.fp16.safetensors")
+    torch.save({}, str(d / "zz.ckpt"))                                     # a *.ckpt wins, as in the reference
+    assert vio.find_vae_checkpoint(str(d))[1].endswith("zz.ckpt")
+
+
 def test_video_and_npz_writers(tmp_path):
     x = torch.linspace(-1.5, 1.5, 3 * 2 * 4 * 4).view(3, 2, 4, 4)
     u8 = vio.video_to_uint8(x)

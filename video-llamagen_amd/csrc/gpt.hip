@@ -67,7 +67,8 @@ struct vlg_gpt {
   unsigned* fault_dev = nullptr;
   int spin_max = 0;                  // option debug_spin_max (0 = default bound)
   bool pdecode = true;               // decode layers as one persistent launch per step (pdecode.hip) where the shape allows
-  int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured default, pd_rows_default())
+  int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured rule of pd_use())
+  int pos_offset = 0;                // benchmarks ("debug_pos_offset"): decode as if this many tokens had already been generated (zeroed cache rows)
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
@@ -407,6 +408,11 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
   }
   if (!strcmp(key, "pdecode")) {
     h->pdecode = value != 0;
+    return VLG_OK;
+  }
+  if (!strcmp(key, "debug_pos_offset")) {
+    VLG_CHECK(value >= 0 && value < (1 << 20), VLG_ERR_BAD_ARG, "debug_pos_offset out of range");
+    h->pos_offset = (int)value;
     return VLG_OK;
   }
   if (!strcmp(key, "pd_rows")) {
@@ -970,7 +976,7 @@ struct Runner {
       hl = ln->hl.as<T>();
     }
     VLG_TRY(head(hl, sp, noise, out_ids, out_lat, trace));
-    return set_state(state(), Tc, 1, st);
+    return set_state(state(), Tc + h->pos_offset, 1, st);   // pos_offset > 0: the rows in between are zero (generate_impl)
   }
 };
 
@@ -1041,9 +1047,9 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                   const float* d_noise, int32_t* out_ids, float* out_lat, float* trace, hipStream_t caller) {
   const bool cfg_on = sp.cfg_scale > 1.0f;
   const int Tc = h->Tc, D = h->D, F = h->F;
-  const int S = round_up(Tc + N, 8);  // gpt.py:322
-  VLG_CHECK(Tc + N <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table (%d positions after %d cond tokens)", N,
-            h->npos - Tc, Tc);
+  const int S = round_up(Tc + h->pos_offset + N, 8);  // gpt.py:322 (+ the benchmark's position offset, normally 0)
+  VLG_CHECK(Tc + h->pos_offset + N <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table (%d positions after %d cond tokens)", N,
+            h->npos - Tc - h->pos_offset, Tc + h->pos_offset);
   if (cfg_on && h->cfg.model_type != VLG_C2I)
     VLG_CHECK(Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
   for (auto& kv : h->w) VLG_CHECK(kv.second.loaded, VLG_ERR_STATE, "weight %s was never loaded", kv.first.c_str());
@@ -1071,6 +1077,10 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   VLG_HIP(hipStreamWaitEvent(r.st, h->ev_in, 0));
   if (d_mask) VLG_HIP(hipMemcpyAsync(ln->maskbuf.p, d_mask, (size_t)B * Tc * sizeof(float), hipMemcpyDeviceToDevice, r.st));
   if (ln->pd_xbuf.p) VLG_HIP(hipMemsetAsync(ln->pd_xbuf.p, 0, ln->pd_xbuf.bytes, r.st));   // hand-off tags count up from the call's first step
+  if (h->pos_offset > 0) {   // late-context timing: cache rows Tc .. Tc + offset - 1 are read by every step and never written
+    VLG_HIP(hipMemsetAsync(ln->kcache.p, 0, ln->kcache.bytes, r.st));
+    VLG_HIP(hipMemsetAsync(ln->vcache.p, 0, ln->vcache.bytes, r.st));
+  }
   VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   hipStream_t s0 = r.st;
   const int steps = N - 1;
@@ -1126,7 +1136,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
-                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows};
+                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset};
       {
         const auto pk = ln->ptr_key();
         key.insert(key.end(), pk.begin(), pk.end());

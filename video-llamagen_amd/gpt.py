@@ -115,6 +115,7 @@ class Transformer:
         self.check_faults = True  # generate(): wait for the call and raise on a device-side time-out (False: asynchronous, see status())
         self.debug_spin_max = 0   # tests: spin bound of the persistent kernels' in-launch waits (0 = default)
         self.pdecode = True      # decode: all layers of a step as one persistent launch (csrc/pdecode.hip) where the shape allows (<= 16 rows)
+        self.debug_pos_offset = 0  # benchmarks: decode as if this many tokens had already been generated (zeroed cache rows): late-context timing
         self.pd_rows = 0         # ... up to this many cache rows (0 = the library's measured default)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
 

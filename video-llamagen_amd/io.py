@@ -3,7 +3,10 @@
 Reference behaviour restated:
 * GPT checkpoints (sample_t2i.py:62-69, serve/model_runner.py:184-191): `torch.save` dicts whose weights sit under "model" (DDP
   training), "module" (DeepSpeed) or "state_dict"; `--from-fsdp` files are the raw state dict.
-* CausalVAE directories (modeling_videobase.py:42-53): `config.json` + `*.ckpt`; the LAST ckpt in glob order is used;
+* CausalVAE directories (modeling_videobase.py:42-53): `config.json` + `*.ckpt`; the LAST ckpt in glob order is used; a directory without
+  any *.ckpt goes to `super().from_pretrained` = diffusers `ModelMixin.from_pretrained` (third-party, not vendored: restated from its
+  published behaviour): `config.json` + `diffusion_pytorch_model[.variant].safetensors`, else `diffusion_pytorch_model[.variant].bin`,
+  optionally under `subfolder`; the file holds the plain state dict (no "state_dict" / EMA wrapper);
   `init_from_ckpt` (modeling_causalvae.py:578-601) prefers a non-empty "ema_state_dict" (unless NOT_USE_EMA_MODEL is set), strips
   "module." prefixes, else takes "state_dict" (its "gen_model" entry when present), drops `ignore_keys` prefixes, loads strictly.
 * custom_to_video (sample_t2v_1f_diff.py:49-58): clamp to [-1, 1], (x + 1) / 2, [C,T,H,W] -> [T,H,W,C], (255 * x) truncated to uint8.
@@ -48,15 +51,34 @@ def select_vae_state_dict(sd, ignore_keys=(), use_ema=None):
     return sd
 
 
-def find_vae_checkpoint(directory, config_name="config.json"):
-    """modeling_videobase.py:44-50 -> (config dict, path of the ckpt file to load)."""
+DIFFUSERS_WEIGHTS = "diffusion_pytorch_model"     # diffusers.utils.{SAFETENSORS_,}WEIGHTS_NAME stem
+
+
+def find_vae_checkpoint(directory, config_name="config.json", subfolder=None, variant=None):
+    """modeling_videobase.py:44-53 -> (config dict, path of the weight file to load).  `*.ckpt` directories first (the last file in glob
+    order, as the reference); otherwise the diffusers layout its `super().from_pretrained` reads: safetensors preferred, then .bin."""
     ckpt_files = glob.glob(os.path.join(directory, "*.ckpt"))
-    if not ckpt_files:
-        raise FileNotFoundError("no *.ckpt under %s (the diffusers safetensors layout is not supported)" % directory)
-    with open(os.path.join(directory, config_name)) as f:
+    if ckpt_files:
+        path, cdir = ckpt_files[-1], directory
+    else:
+        cdir = os.path.join(directory, subfolder) if subfolder else directory
+        stem = DIFFUSERS_WEIGHTS + ("." + variant if variant else "")
+        cands = [os.path.join(cdir, stem + ext) for ext in (".safetensors", ".bin")]
+        path = next((c for c in cands if os.path.isfile(c)), None)
+        if path is None:
+            raise FileNotFoundError("no *.ckpt under %s and none of %s" % (directory, ", ".join(os.path.basename(c) for c in cands)))
+    with open(os.path.join(cdir, config_name)) as f:
         cfg = json.load(f)
     cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}       # diffusers bookkeeping keys (_class_name, _diffusers_version)
-    return cfg, ckpt_files[-1]
+    return cfg, path
+
+
+def load_vae_weight_file(path):
+    """-> the object `select_vae_state_dict` takes: a torch.load'ed checkpoint dict, or the plain state dict of a diffusers file."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path, device="cpu")
+    return torch.load(path, map_location="cpu")
 
 
 def video_to_uint8(x):

@@ -61,13 +61,18 @@ class CausalVAEModel:
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
-        """modeling_videobase.py:42-53: directory with config.json + *.ckpt (the last one in glob order is loaded)."""
+        """modeling_videobase.py:42-53: directory with config.json + *.ckpt (the last one in glob order is loaded through init_from_ckpt);
+        without a *.ckpt the diffusers layout of `super().from_pretrained`: diffusion_pytorch_model[.variant].safetensors / .bin, optional
+        `subfolder`, the plain state dict loaded strictly."""
         from . import io as vio
-        cfg, ckpt = vio.find_vae_checkpoint(pretrained_model_name_or_path)
+        cfg, path = vio.find_vae_checkpoint(pretrained_model_name_or_path, subfolder=kwargs.get("subfolder"), variant=kwargs.get("variant"))
         model = cls.from_config(cfg)
-        if "device" in kwargs or "dtype" in kwargs:
-            model.to(kwargs.get("device"), kwargs.get("dtype"))
-        model.init_from_ckpt(ckpt)
+        if "device" in kwargs or "dtype" in kwargs or "torch_dtype" in kwargs:
+            model.to(kwargs.get("device"), kwargs.get("dtype", kwargs.get("torch_dtype")))
+        if path.endswith(".ckpt"):
+            model.init_from_ckpt(path)
+        else:
+            model.load_state_dict(dict(vio.load_vae_weight_file(path)), strict=True)
         return model
 
     def init_from_ckpt(self, path, ignore_keys=()):
