@@ -436,6 +436,35 @@ def test_diffloss_persistent_sampler_vs_oracle_and_launch_chain(B):
     assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize("B", [2, 6, 8])
+def test_diffloss_persistent_sampler_guidance_pairs(B):
+    """DiffLoss.sample's own guidance (cfg_iter != 1: forward_with_cfg, diffloss.py:37-41,240-248) INSIDE the persistent sampler: a
+    4-row group serves two (conditional, unconditional) pairs, eps = u + cfg (c - u) is formed where both rows' network outputs meet.
+    Against the oracle (pinned by the reference's DiffLoss.sample golden, t2vdiff.npz dlcfg_latents) and against the launch chain;
+    6 rows = 3 pairs = one full group + a group with a single pair; depth 3 (resident-weight instance) and depth 2 (streamed)."""
+    import video_llamagen_amd as V
+    for depth in (3, 2):
+        m, cfg, sd = _diff_model_w(torch.float32, 256, 10, depth=depth)
+        C, N, S = cfg["vae_embed_dim"], 4, 10
+        noise = cases.rng(71).standard_normal((N, S + 1, B, C), dtype=np.float32)
+        c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4, 3, 6][:B])
+        om = O.GPTOracle(cfg, sd, "fp32")
+        ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.8, cfg_iter=1.8)
+        out = {}
+        for persist in (True, False):
+            m.dl_persist = persist
+            out[persist] = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.8, cfg_iter=1.8,
+                                                noise=torch.from_numpy(noise)))
+            assert np.isfinite(out[persist]).all()
+            assert np.abs(out[persist] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), (persist, depth)
+        assert np.abs(out[True] - out[False]).max() < 2e-4 * max(1.0, np.abs(ref).max())
+        m.dl_persist = True
+        plain = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.8, noise=torch.from_numpy(noise)))
+        assert np.abs(plain - out[True]).max() > 1e-3          # guidance does something; and cfg_iter = 1 afterwards is the plain sampler
+        refn = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.8)
+        assert np.abs(plain - refn).max() < 1e-3 * max(1.0, np.abs(refn).max())
+
+
 @pytest.mark.parametrize("width,depth", [(512, 3), (256, 2), (768, 3), (512, 4)])
 def test_diffloss_persistent_sampler_kernel_variants(width, depth):
     """The other instantiations of the persistent sampler against the oracle and the launch chain (fp32): W 512 = one K block per wave with

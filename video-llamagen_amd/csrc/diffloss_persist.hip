@@ -223,8 +223,18 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     tile = (P % 8 == 0) ? (j % 8) * (P / 8) + j / 8 : j;
   }
   const int col0 = tile * DP_TC;
-  const int row0 = grp * DP_R;                 // first batch row of the group
-  const int nrow = (p.B - row0) < DP_R ? (p.B - row0) : DP_R;
+  // local row j of the group <-> batch row.  Plain: rows 4 grp .. 4 grp + 3.  Guidance (n_half = B / 2 > 0, DiffLoss.sample's cfg,
+  // diffloss.py:37-41): the group serves the PAIRS 2 grp and 2 grp + 1 - local rows 0, 1 are their conditional rows (batch rows pair),
+  // local rows 2, 3 their unconditional partners (batch rows pair + n_half), so that a pair's two network outputs meet in one workgroup.
+  const int n_half = p.n_half;
+  auto row_valid = [&](int j) { return n_half ? (2 * grp + (j & 1)) < n_half : (grp * DP_R + j) < p.B; };
+  auto row_batch = [&](int j) {   // batch row of local row j (an invalid local row maps to the group's first row: a valid address)
+    if (n_half) {
+      const int pair = row_valid(j) ? 2 * grp + (j & 1) : 2 * grp;
+      return pair + (row_valid(j) ? (j >> 1) : 0) * n_half;
+    }
+    return row_valid(j) ? grp * DP_R + j : grp * DP_R;
+  };
   const int step_tok = p.state->step;
   unsigned epoch = 0;
   // exchange buffer: [parity][workgroup][NWD] 8-byte units {4 bytes of the tile, epoch tag}
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   dp_u32x4_t vsc[NKBW], vsh[NKBW];       // rows of the next LayerNorm
   dp_u32x4_t vsc2[NKBW], vsh2[NKBW];     // rows of the next reverse step's first LayerNorm (requested while the final layer's rows are still in use)
   auto prefetch_mod = [&](dp_u32x4_t (&rsc)[NKBW], dp_u32x4_t (&rsh)[NKBW], const T* shift, const T* scale) {
-    const int grow = (row0 + wave) < p.B ? (row0 + wave) : p.B - 1;
+    const int grow = row_batch(wave);
     const dp_u32x4_t* scg = reinterpret_cast<const dp_u32x4_t*>(scale + (size_t)grow * MR);
     const dp_u32x4_t* shg = reinterpret_cast<const dp_u32x4_t*>(shift + (size_t)grow * MR);
 #pragma unroll
@@ -285,7 +295,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     float s = 0.f;
     float xr[8];
     if constexpr (decltype(FROMX)::value) {
-      const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + row * 16 + 4);
+      const int xrow = n_half ? (row & 1) : row;   // guidance: both rows of a pair are evaluated on the CONDITIONAL row's x_t (diffloss.py:38-39)
+      const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16 + 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         xr[c] = a[c];
@@ -485,8 +496,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   if (tid < DP_R * 16) {
     const int row = tid / 16, c = tid % 16;
     float v = 0.f;
-    if (c < C && row < nrow) {
-      const int b = row0 + row;
+    if (c < C && row_valid(row)) {
+      const int b = n_half ? row_batch(row) % n_half : row_batch(row);   // one x_T draw per pair (diffloss.py:38-39)
       v = p.noise ? p.noise[(((size_t)step_tok * (S + 1)) * p.B_total + p.b_off + b) * C + c]
                   : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, 0u);
       v = DT<T>::rt(v);
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   // wave 0: this lane's two elements of the published [R][32] tile
   const int e0 = elem(0), e1 = elem(1);
   const int prow0 = e0 / DP_TC, pc0 = e0 % DP_TC, prow1 = e1 / DP_TC, pc1 = e1 % DP_TC;
-  const int pg0 = (row0 + prow0) < p.B ? (row0 + prow0) : p.B - 1, pg1 = (row0 + prow1) < p.B ? (row0 + prow1) : p.B - 1;
+  const int pg0 = row_batch(prow0), pg1 = row_batch(prow1);
   {
     const T* mod = reinterpret_cast<const T*>(p.mod_all) + (size_t)(S - 1) * p.B * MR;
     prefetch_mod(vsc, vsh, mod, mod + W);
@@ -568,9 +579,9 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
         g1r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg1 * MR + 2 * W + col0 + pc1);
         if (blk == 0) {
           const int row = lane / 16, c = lane % 16;
-          if (c < C && row < nrow) {
+          if (c < C && row_valid(row)) {
             cf = p.coef[i];
-            const int b = row0 + row;
+            const int b = row_batch(row);
             nz = p.noise ? p.noise[(((size_t)step_tok * (S + 1) + 1 + k) * p.B_total + p.b_off + b) * C + c]
                          : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, (uint32_t)(1 + k));
           }
@@ -658,9 +669,14 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       // p_sample (gaussian_diffusion.py:254-332,376-420): learned-range variance, eps prediction, clip_denoised = False
       if (tid < DP_R * 16) {
         const int row = tid / 16, c = tid % 16;
-        if (c < C && row < nrow) {
+        if (c < C && row_valid(row)) {
           const float* cs = cfs + tid * 8;       // {sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log, nonzero, noise} of this step
-          const float eps = dp_rt<T>(reduced(0, row, c) + bfin_s[c]), v = dp_rt<T>(reduced(0, row, C + c) + bfin_s[C + c]);   // final layer outputs (eps | v)
+          float eps = dp_rt<T>(reduced(0, row, c) + bfin_s[c]);
+          const float v = dp_rt<T>(reduced(0, row, C + c) + bfin_s[C + c]);   // final layer outputs (eps | v)
+          if (n_half) {   // forward_with_cfg (diffloss.py:240-248): eps = u + cfg (c - u) from the pair's two rows; variance, draw and x_t stay per row
+            const float ce = dp_rt<T>(reduced(0, row & 1, c) + bfin_s[c]), ue = dp_rt<T>(reduced(0, 2 + (row & 1), c) + bfin_s[c]);
+            eps = dp_rt<T>(ue + dp_rt<T>(p.cfg * dp_rt<T>(ce - ue)));
+          }
           const float xv = xs[row * 16 + c];
           const float frac = (v + 1.0f) / 2.0f;
           const float logvar = frac * cs[5] + (1.0f - frac) * cs[4];
@@ -684,8 +700,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   // ---- results: the workgroup of column tile 0 writes its group's rows (NaN when an exchange timed out) -------------------------
   if (tile == 0 && tid < DP_R * 16) {
     const int row = tid / 16, c = tid % 16;
-    if (c < C && row < nrow) {
-      const int b = row0 + row;
+    if (c < C && row_valid(row)) {
+      const int b = row_batch(row);
       const float v = alive ? xs[row * 16 + c] : __int_as_float(0x7fc00000);
       p.cur[(size_t)b * C + c] = v;
       p.out_lat[((size_t)b * p.N + step_tok) * C + c] = v;

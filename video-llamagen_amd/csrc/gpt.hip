@@ -791,13 +791,13 @@ struct Runner {
     }
     const T* wip = W<T>(p + "input_proj.weight");
     const T* bip = W<T>(p + "input_proj.bias");
-    const bool dcfg = h->cfg_iter != 1.0f;   // forward_with_cfg: the launch chain below (the persistent kernel keeps rows independent)
+    const bool dcfg = h->cfg_iter != 1.0f;   // forward_with_cfg: pairs (b, b + B/2) - in one 4-row group of the persistent kernel, or the chain below
     const int n_half = dcfg ? B / 2 : 0;
     if (dcfg && B % 2 != 0) {
       set_error("cfg_iter != 1 pairs row b with row b + B/2 (diffloss.py:38-39): it needs an even batch, got %d rows", B);
       return VLG_ERR_BAD_SHAPE;
     }
-    if (h->dl_persist_on && !dcfg && dl_persist_ok<T>(B, Wd, C, dd)) {
+    if (h->dl_persist_on && dl_persist_ok<T>(B, Wd, C, dd)) {
       // all S reverse steps in one persistent launch (2 depth all-gathers per step between the workgroups of a 4-row group)
       DlPersist dp{};
       for (int blk = 0; blk < dd; ++blk) {
@@ -826,6 +826,8 @@ struct Runner {
       dp.seed = sp.seed;
       dp.fault = h->fault_dev;
       dp.spin_max = h->spin_max > 0 ? h->spin_max : (1 << 20);
+      dp.n_half = n_half;
+      dp.cfg = h->cfg_iter;
       return dl_persist<T>(dp, st);
     }
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue

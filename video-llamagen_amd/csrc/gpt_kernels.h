@@ -200,6 +200,8 @@ struct DlPersist {
   uint64_t seed;
   unsigned* fault;       // host-visible fault word of the handle (vlg_gpt_status): set when an exchange wait runs out
   int spin_max;          // spin bound of every wait (default 1 << 20; option debug_spin_max)
+  int n_half;            // 0, or B / 2: DiffLoss.sample's guidance pairs rows (b, b + B/2) as (conditional, unconditional)
+  float cfg;             // ... with this scale (eps = u + cfg (c - u))
 };
 constexpr unsigned kFaultDlPersist = 0x444C0000u;   // 'DL' | reverse step index
 constexpr unsigned kFaultDecode = 0x50440000u;      // 'PD' | phase index
