@@ -119,6 +119,8 @@ struct Tensor {
   DevBuf buf;
   std::vector<int64_t> shape;
   bool loaded = false;
+  DevBuf fm;             // fragment-major copy of a Linear weight (gpt_kernels.h: relayout_fragment_major), built lazily
+  bool fm_stale = true;  // set by every (partial) load of the tensor
   int64_t numel() const {
     int64_t n = 1;
     for (auto s : shape) n *= s;

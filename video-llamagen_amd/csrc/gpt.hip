@@ -118,6 +118,10 @@ struct vlg_gpt {
     for (auto e : attn_ev) (void)hipEventDestroy(e);
   }
   const void* W(const std::string& n) const { return w.at(n).buf.p; }
+  const void* Wfm(const std::string& n) const {   // fragment-major copy, or null where the shape does not tile / it was never built
+    const Tensor& t = w.at(n);
+    return t.fm_stale ? nullptr : t.fm.p;
+  }
 };
 
 // create_diffusion(timestep_respacing=str(n), noise_schedule="cosine", learn_sigma=True): diffusion/__init__.py:11-47,
@@ -369,6 +373,7 @@ extern "C" int vlg_gpt_load_tensor(vlg_gpt_t* h, const char* name, const void* d
   char* dst = (char*)t.buf.p + (size_t)sp.row_off * row_elems * h->esz;
   VLG_TRY(upload_convert(dst, h->dtype, data, src_dtype, src_on_device, n, h->s_int));
   t.loaded = true;
+  t.fm_stale = true;
   if (consumed) *consumed = 1;
   return VLG_OK;
 }
@@ -482,6 +487,28 @@ extern "C" int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* wb, double* 
 
 namespace {
 
+// fragment-major copies of the four Linear weights of every layer (gpt_kernels.h: relayout_fragment_major), rebuilt after a (re)load.
+// Twice the weight memory for these tensors - 1.5 GB more for GPT-XL, 6 GB for GPT-3B, on a 288 GB part.
+template <typename T>
+int ensure_fm(vlg_gpt* h) {
+  bool any = false;
+  for (int l = 0; l < h->L; ++l) {
+    const std::string p = "layers." + std::to_string(l) + ".";
+    for (const char* nm : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13", "feed_forward.w2.weight"}) {
+      Tensor& t = h->w.at(p + nm);
+      if (!t.fm_stale || !t.loaded || t.shape.size() != 2) continue;
+      const int N = (int)t.shape[0], K = (int)t.shape[1];
+      if (!fragment_major_ok(N, K, (int)sizeof(T))) continue;
+      VLG_TRY(t.fm.reserve((size_t)N * K * sizeof(T)));
+      VLG_TRY(relayout_fragment_major<T>(reinterpret_cast<const T*>(t.buf.p), reinterpret_cast<T*>(t.fm.p), N, K, h->s_int));
+      t.fm_stale = false;
+      any = true;
+    }
+  }
+  if (any) VLG_HIP(hipStreamSynchronize(h->s_int));
+  return VLG_OK;
+}
+
 // PdLayer[L] for the persistent decode kernel: weight buffers are allocated at create, so the pointers never change (built outside of
 // any stream capture)
 int ensure_pd_layers(vlg_gpt* h) {
@@ -525,6 +552,10 @@ struct Runner {
   const U* W(const std::string& n) {
     return reinterpret_cast<const U*>(h->W(n));
   }
+  template <typename U>
+  const U* Wfm(const std::string& n) {
+    return reinterpret_cast<const U*>(h->Wfm(n));
+  }
 
   int linear(const T* x, const std::string& wname, T* out, float* out_f32, int M, int Nn, int K, int act) {
     int sp = 1;
@@ -545,7 +576,7 @@ struct Runner {
       int sp = 1;
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
       T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
-      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st));
+      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st, Wfm<T>(p + "attention.wqkv.weight")));
       VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos, pages));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
@@ -554,13 +585,13 @@ struct Runner {
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
                            h->Tc, st, e0, e1, row_pos, pages));
-      VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st));
+      VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st, Wfm<T>(p + "attention.wo.weight")));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
-        VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st));
+        VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st, Wfm<T>(p + "feed_forward.w13")));
         VLG_TRY(reduce_silu_mul<T>(ws, sp, ln->g.as<T>(), M, F, st));
       }
-      VLG_TRY(gemm_slabs<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st));
+      VLG_TRY(gemm_slabs<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st, Wfm<T>(p + "feed_forward.w2.weight")));
       const std::string nxt = (l + 1 < h->L) ? "layers." + std::to_string(l + 1) + ".attention_norm.weight" : std::string("norm.weight");
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(nxt), xn, M, D, h->cfg.norm_eps, st));
     }
@@ -1067,6 +1098,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   Lane* ln = &h->lane;
   VLG_TRY(reserve_lane(h, *ln, B, cfg_on ? 2 * B : B, S));
   VLG_TRY(ensure_pd_layers(h));
+  VLG_TRY(ensure_fm<T>(h));
   if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)B * Tc * sizeof(float)));
   Runner<T> r{h, ln, ln->st, B, cfg_on ? 2 * B : B, N, S, 0, B, d_mask ? ln->maskbuf.as<float>() : nullptr};
   if (h->cfg.head == VLG_HEAD_HIDDEN) {
@@ -1238,6 +1270,7 @@ struct vlg_gpt::Session {
 namespace {
 template <typename T>
 int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& sp) {
+  VLG_TRY(ensure_fm<T>(h));
   auto ses = std::make_unique<vlg_gpt::Session>();
   ses->R = R;
   ses->cfg = sp.cfg_scale > 1.0f;

@@ -33,7 +33,16 @@ enum Act { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_SILU = 2 };
 // ---- GEMM: slabs[s][M][N] (fp32 partial sums over a K slice) = x[M,K] @ w[N,K]^T -----------------
 // returns the number of slabs written through *splits (>= 1).  `ws` must hold max_splits*M*N floats.
 template <typename T>
-int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits, hipStream_t st);
+int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits, hipStream_t st, const T* wfm = nullptr);
+// FRAGMENT-MAJOR copy of a Linear weight [N][K] (N % 16 == 0, K * sizeof(T) % 64 == 0).  nn.Linear keeps K contiguous per output row,
+// and an MFMA B fragment of 16 output columns x 64 bytes of K is then 16 pieces of 64 bytes from 16 rows: every load instruction of a
+// wave touches 16 HALF cache lines, and a cold weight stream runs 1.5-1.9x slower than one made of whole lines
+// (tools/microbench/frag_lab.hip: GPT-3B w13, 111 MB, 272 workgroups: 39.4 vs 26.1 us).  Here block (t, s) = the fragment of rows
+// 16 t .. 16 t + 15, K bytes [64 s, 64 s + 64) is 1 KB contiguous at ((t * nks + s) * 1024), lane l = r + 16 q (row r, 16-byte chunk q)
+// at l * 16: one wave instruction = 8 whole lines.  A pure permutation: same values, same MFMA operands, same results.
+template <typename T>
+int relayout_fragment_major(const T* w, T* out, int N, int K, hipStream_t st);
+inline bool fragment_major_ok(int N, int K, int esz) { return N % 16 == 0 && ((long long)K * esz) % 64 == 0; }
 int gemm_max_splits();
 // fused SwiGLU up-projection: g = rt(rt(silu(rt(x w1^T))) * rt(x w3^T)), w13 = [w1; w3]; false -> use the generic path
 template <typename T>

@@ -309,6 +309,112 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64 rows x (64 NTW) columns per workgroup for ONE row block (32 < M <= 64: decode at 64 cache rows, BASELINE config 5).  In
+// gemm_wide_kernel every byte of weights is matched by a byte of activations through the compute unit's vector-memory pipe (64 x 64
+// tile), which holds about 64 KB of requests at a time: half of that window carries activations that every workgroup re-reads from L2,
+// and the weights stream at 2.4 TB/s.  Here a wave owns NTW 16-column tiles (NTW = 4: 256 columns per workgroup, 4 bytes of weights
+// per byte of activations), a whole K block of them (16 NTW KB per workgroup) is requested one block ahead into registers, and the
+// activation tile still goes through LDS once per workgroup.  One workgroup per compute unit in one round: columns x K slices are chosen
+// so that the grid is just above the CU count (gemm_plan).  Output: fp32 slabs, consumed by the reduce_* kernels (same rounding points).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NTW, bool FM>   // FM: w is the fragment-major copy (gpt_kernels.h: relayout_fragment_major)
+__global__ __launch_bounds__(256) void gemm_tall_kernel(const T* __restrict__ x, const T* __restrict__ w, float* __restrict__ slabs, int M,
+                                                        int N, int K) {
+  constexpr int KBLK = GemmT<T>::KBLK;   // 256 bytes per row per K block for both dtypes
+  __shared__ u32x4_t As[2][64 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * (64 * NTW) + wave * (16 * NTW);
+  const int split = blockIdx.z, splits = gridDim.z;
+  const int nkb = K / KBLK;
+  constexpr int CPB = KBLK * (int)sizeof(T) / 16;   // 16-byte chunks per row per K block = 16
+
+  const u32x4_t* asrc[4];
+  int aslot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int row = c >> 4, ch = c & 15;
+    const int gr = row < M ? row : M - 1;
+    asrc[i] = reinterpret_cast<const u32x4_t*>(x + (size_t)gr * K) + ch;
+    aslot[i] = row * 16 + (ch ^ (row & 15));
+  }
+  // weight chunk s2 of K block kb of tile nt: row-major = row (n0 + 16 nt + r), 16-byte chunk kb * 16 + 4 s2 + q;
+  // fragment-major = block (tile, K step 4 kb + s2), 16-byte slot `lane`
+  const u32x4_t* wsrc[NTW];
+  constexpr int WSTEP = FM ? 64 : 4;      // u32x4 units between the K steps of a block
+  constexpr int WBLK = FM ? 256 : CPB;    // ... between K blocks
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    if constexpr (FM)
+      wsrc[nt] = reinterpret_cast<const u32x4_t*>(w) + (size_t)(n0 / 16 + nt) * ((size_t)nkb * 256) + lane;
+    else
+      wsrc[nt] = reinterpret_cast<const u32x4_t*>(w + (size_t)(n0 + nt * 16 + r) * K) + q;
+  }
+
+  f32x4_t acc[NTW][4];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t ra[4], b[NTW][4], bn[NTW][4];
+  int kb = split;
+  if (kb < nkb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kb * CPB];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) b[nt][s2] = __builtin_nontemporal_load(wsrc[nt] + (size_t)kb * WBLK + s2 * WSTEP);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) As[0][aslot[i]] = ra[i];
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; kb < nkb; kb += splits) {
+    const int kn = kb + splits;
+    const bool more = kn < nkb;
+    const int kl = more ? kn : kb;   // unconditional loads (the last iteration re-reads its own block): counted waits stay exact
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kl * CPB];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) bn[nt][s2] = __builtin_nontemporal_load(wsrc[nt] + (size_t)kl * WBLK + s2 * WSTEP);
+    u32x4_t af[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = mt * 16 + r;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) af[mt][s2] = As[buf][row * 16 + ((s2 * 4 + q) ^ (row & 15))];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) mfma_block<T, 4>(af, b[nt], acc[nt]);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[buf ^ 1][aslot[i]] = ra[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) b[nt][s2] = bn[nt][s2];
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = mt * 16 + q * 4 + e;
+        if (row < M) slabs[((size_t)split * M + row) * N + n0 + nt * 16 + r] = acc[nt][mt][e];
+      }
+    }
+}
+
 // fallback for shapes the MFMA kernel does not tile (K % KBLK != 0 or N % 16 != 0: adapters with
 // vae_embed_dim = 8, toy widths): one wave per output element, lanes stride over K.
 template <typename T>
@@ -330,15 +436,34 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const T* __restrict__ x
 int gemm_max_splits() { return 8; }
 
 // launch geometry shared by gemm_slabs and the workspace sizing
-static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits, bool* wide = nullptr) {
+static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits, bool* wide = nullptr, int* tall = nullptr) {
   naive = (K % kblk != 0) || (N % 16 != 0);
   mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   mchunks = cdiv(M, mt * 16);
   splits = 1;
   if (wide) *wide = false;
+  if (tall) *tall = 0;
   if (naive) return;
   const int nkb = K / kblk;
   static const bool wide_off = getenv("VLG_GEMM_WIDE") != nullptr && atoi(getenv("VLG_GEMM_WIDE")) == 0;   // A/B knob
+  static const bool tall_off = getenv("VLG_GEMM_TALL") != nullptr && atoi(getenv("VLG_GEMM_TALL")) == 0;   // A/B knob
+  if (M > 32 && mchunks == 1 && !wide_off && !tall_off) {
+    // gemm_tall_kernel: the widest column tile (64 NTW) that divides N and still leaves every K slice >= 2 K blocks; K slices so that the
+    // grid is ONE round of workgroups on the 256 compute units (GPT-3B: qkv 50 tiles x 5, wo / w2 25 x 10, w13 68 x 3)
+    for (int ntw = 4; ntw >= 2; --ntw) {
+      if (N % (64 * ntw) != 0) continue;
+      const int tiles = N / (64 * ntw);
+      int sp = 256 / tiles;                    // one round: a compute unit with two workgroups would take twice as long as the others
+      if (sp > nkb / 2) sp = nkb / 2;
+      if (sp > gemm_max_splits()) sp = gemm_max_splits();   // the reduce_* kernels merge up to 8 slabs
+      if (sp < 1) sp = 1;
+      if (tiles * sp < 160) continue;          // too few workgroups to stream from: a narrower tile
+      splits = sp;
+      if (wide) *wide = true;
+      if (tall) *tall = ntw;
+      return;
+    }
+  }
   if (M > 32 && N % 64 == 0 && !wide_off) {   // gemm_wide_kernel: 64 x 64 tiles, K slices so that ~3 workgroups per CU stream
     if (wide) *wide = true;
     splits = 768 / ((N / 64) * mchunks);
@@ -362,19 +487,34 @@ size_t gemm_ws_floats(int M, int N, int K, int elem_size) {
 }
 
 template <typename T>
-int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits_out, hipStream_t st) {
+int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* splits_out, hipStream_t st, const T* wfm) {
   constexpr int KBLK = GemmT<T>::KBLK;
   if (M <= 0 || N <= 0 || K <= 0) {
     set_error("gemm: bad shape %d %d %d", M, N, K);
     return VLG_ERR_BAD_SHAPE;
   }
   bool naive, wide;
-  int mt, mchunks, splits;
-  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits, &wide);
+  int mt, mchunks, splits, tall;
+  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits, &wide, &tall);
   if (naive) {
     const long long total = (long long)M * N;
     gemm_naive_kernel<T><<<dim3((unsigned)((total + 3) / 4)), 256, 0, st>>>(x, w, ws, M, N, K);
     *splits_out = 1;
+    return VLG_OK;
+  }
+  if (tall) {
+    const dim3 grid(N / (64 * tall), 1, splits);
+    static const bool fm_off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;   // A/B knob
+    if (wfm != nullptr && !fm_off) {
+      if (tall == 4) gemm_tall_kernel<T, 4, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
+      else if (tall == 3) gemm_tall_kernel<T, 3, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
+      else gemm_tall_kernel<T, 2, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
+    } else {
+      if (tall == 4) gemm_tall_kernel<T, 4, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+      else if (tall == 3) gemm_tall_kernel<T, 3, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+      else gemm_tall_kernel<T, 2, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
+    }
+    *splits_out = splits;
     return VLG_OK;
   }
   if (wide) {
@@ -416,8 +556,33 @@ bool gemm_swiglu(const T* x, const T* w13, T* g, int M, int F, int K, hipStream_
 }
 template bool gemm_swiglu<float>(const float*, const float*, float*, int, int, int, hipStream_t);
 template bool gemm_swiglu<bf16>(const bf16*, const bf16*, bf16*, int, int, int, hipStream_t);
-template int gemm_slabs<float>(const float*, const float*, float*, int, int, int, int*, hipStream_t);
-template int gemm_slabs<bf16>(const bf16*, const bf16*, float*, int, int, int, int*, hipStream_t);
+template int gemm_slabs<float>(const float*, const float*, float*, int, int, int, int*, hipStream_t, const float*);
+template int gemm_slabs<bf16>(const bf16*, const bf16*, float*, int, int, int, int*, hipStream_t, const bf16*);
+
+// out block (t, s), 16-byte slot l = r + 16 q  <-  row 16 t + r, bytes [64 s + 16 q, + 16)
+__global__ __launch_bounds__(256) void relayout_fm_kernel(const u32x4_t* __restrict__ w, u32x4_t* __restrict__ out, long long chunks, int nks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= chunks) return;
+  const int l = (int)(i & 63);
+  const long long blk = i >> 6;
+  const long long t = blk / nks;
+  const int s = (int)(blk - t * nks);
+  const int r = l & 15, q = l >> 4;
+  out[i] = w[(t * 16 + r) * (long long)(nks * 4) + s * 4 + q];
+}
+template <typename T>
+int relayout_fragment_major(const T* w, T* out, int N, int K, hipStream_t st) {
+  if (!fragment_major_ok(N, K, (int)sizeof(T))) {
+    set_error("relayout_fragment_major: [%d][%d] does not tile", N, K);
+    return VLG_ERR_BAD_SHAPE;
+  }
+  const long long chunks = (long long)N * K * (long long)sizeof(T) / 16;
+  relayout_fm_kernel<<<dim3((unsigned)((chunks + 255) / 256)), 256, 0, st>>>(reinterpret_cast<const u32x4_t*>(w), reinterpret_cast<u32x4_t*>(out), chunks,
+                                                                              (int)((long long)K * sizeof(T) / 64));
+  return VLG_OK;
+}
+template int relayout_fragment_major<float>(const float*, float*, int, int, hipStream_t);
+template int relayout_fragment_major<bf16>(const bf16*, bf16*, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // slab-reduce epilogues
