@@ -70,6 +70,7 @@ struct vlg_gpt {
   int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured rule of pd_use())
   int pos_offset = 0;                // benchmarks ("debug_pos_offset"): decode as if this many tokens had already been generated (zeroed cache rows)
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
+  bool pd_fm = false;                // ... which are the fragment-major copies
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
   bool dtemb_ready = false;
 
@@ -505,19 +506,40 @@ int ensure_fm(vlg_gpt* h) {
       any = true;
     }
   }
+  // the per-step GEMMs of the fused decode path (token head: V x D, as large as a layer; latent adapters; DiffLoss condition embedding)
+  for (const char* nm : {"output.weight", "vae_latent_adapter.fc2.weight", "vae_latent_adapter2.fc1.weight", "diffloss.net.cond_embed.weight"}) {
+    auto it = h->w.find(nm);
+    if (it == h->w.end()) continue;
+    Tensor& t = it->second;
+    if (!t.fm_stale || !t.loaded || t.shape.size() != 2) continue;
+    const int N = (int)t.shape[0], K = (int)t.shape[1];
+    if (!fragment_major_ok(N, K, (int)sizeof(T))) continue;
+    VLG_TRY(t.fm.reserve((size_t)N * K * sizeof(T)));
+    VLG_TRY(relayout_fragment_major<T>(reinterpret_cast<const T*>(t.buf.p), reinterpret_cast<T*>(t.fm.p), N, K, h->s_int));
+    t.fm_stale = false;
+    any = true;
+  }
   if (any) VLG_HIP(hipStreamSynchronize(h->s_int));
   return VLG_OK;
 }
 
 // PdLayer[L] for the persistent decode kernel: weight buffers are allocated at create, so the pointers never change (built outside of
 // any stream capture)
-int ensure_pd_layers(vlg_gpt* h) {
-  if (h->pd_layers_dev.p != nullptr) return VLG_OK;
+int ensure_pd_layers(vlg_gpt* h) {   // after ensure_fm: the table points at the fragment-major copies when every layer has them
+  static const bool fm_off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;
+  bool fm = !fm_off;
+  for (int l = 0; l < h->L && fm; ++l) {
+    const std::string p = "layers." + std::to_string(l) + ".";
+    for (const char* nm : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13", "feed_forward.w2.weight"}) fm = fm && h->Wfm(p + nm) != nullptr;
+  }
+  if (h->pd_layers_dev.p != nullptr && h->pd_fm == fm) return VLG_OK;
+  h->pd_fm = fm;
   std::vector<PdLayer> v(h->L);
   for (int l = 0; l < h->L; ++l) {
     const std::string p = "layers." + std::to_string(l) + ".";
-    v[l] = PdLayer{h->W(p + "attention.wqkv.weight"), h->W(p + "attention.wo.weight"), h->W(p + "feed_forward.w13"),
-                   h->W(p + "feed_forward.w2.weight"), h->W(p + "attention_norm.weight"), h->W(p + "ffn_norm.weight")};
+    auto wp = [&](const char* nm) { return fm ? h->Wfm(p + nm) : h->W(p + nm); };
+    v[l] = PdLayer{wp("attention.wqkv.weight"), wp("attention.wo.weight"), wp("feed_forward.w13"),
+                   wp("feed_forward.w2.weight"), h->W(p + "attention_norm.weight"), h->W(p + "ffn_norm.weight")};
   }
   VLG_TRY(h->pd_layers_dev.reserve(v.size() * sizeof(PdLayer)));
   VLG_HIP(hipMemcpy(h->pd_layers_dev.p, v.data(), v.size() * sizeof(PdLayer), hipMemcpyHostToDevice));
@@ -613,10 +635,15 @@ struct Runner {
     if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, pro, EPI_STORE);
     return ok;
   }
+  static bool fm_on() {   // A/B knob: VLG_GEMM_FM=0 streams the row-major weights everywhere
+    static const bool off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;
+    return !off;
+  }
   // y = epilogue(RMSNorm(x; norm_w) @ w^T): one launch with the norm as the GEMM's prologue, or norm + GEMM where the prologue does not
   // cover K (same rounding points: the explicit kernel is the slab path's, xn rounded to T either way)
-  int norm_gemm(T* x, const T* norm_w, const T* w, int Nn, int K, int epi, FusedGemm& fa) {
+  int norm_gemm(T* x, const T* norm_w, const T* w, int Nn, int K, int epi, FusedGemm& fa, const T* wfm = nullptr) {
     fa.eps = h->cfg.norm_eps;
+    fa.wfm = fm_on() ? wfm : nullptr;
     if (gemm_fused_ok<T>(Bp, Nn, K, true, epi)) {
       fa.norm_w = norm_w;
       return gemm_fused<T>(x, w, Bp, Nn, K, true, epi, fa, st);
@@ -647,7 +674,7 @@ struct Runner {
       fa.H = H;
       fa.hd = hd;
       fa.S = S;
-      VLG_TRY(norm_gemm(x, W<T>(p + "attention_norm.weight"), W<T>(p + "attention.wqkv.weight"), 3 * D, D, EPI_QKV, fa));
+      VLG_TRY(norm_gemm(x, W<T>(p + "attention_norm.weight"), W<T>(p + "attention.wqkv.weight"), 3 * D, D, EPI_QKV, fa, Wfm<T>(p + "attention.wqkv.weight")));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
         e0 = h->attn_ev[2 * ev_slot];
@@ -657,10 +684,12 @@ struct Runner {
                            st, e0, e1, row_pos, pages));
       FusedGemm fr;
       fr.h = x;
+      fr.wfm = fm_on() ? Wfm<T>(p + "attention.wo.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
       fs.out = ln->g.as<T>();
-      VLG_TRY(norm_gemm(x, W<T>(p + "ffn_norm.weight"), W<T>(p + "feed_forward.w13"), F, D, EPI_SWIGLU, fs));
+      VLG_TRY(norm_gemm(x, W<T>(p + "ffn_norm.weight"), W<T>(p + "feed_forward.w13"), F, D, EPI_SWIGLU, fs, Wfm<T>(p + "feed_forward.w13")));
+      fr.wfm = fm_on() ? Wfm<T>(p + "feed_forward.w2.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
     }
     return VLG_OK;
@@ -695,6 +724,7 @@ struct Runner {
     a.xbuf = ln->pd_xbuf.p;
     a.fault = h->fault_dev;
     a.spin_max = h->spin_max;
+    a.fm = h->pd_fm ? 1 : 0;
     a.L = h->L; a.M = Bp; a.D = h->D; a.H = h->H; a.hd = h->hd; a.F = h->F; a.S = S;
     a.eps = h->cfg.norm_eps;
     return pd_layers<T>(a, st);
@@ -707,14 +737,14 @@ struct Runner {
     const T* final_norm = W<T>("norm.weight");
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       fa.out_f32 = ln->logits.as<float>();
-      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("output.weight"), h->V, D, EPI_STORE, fa));
+      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("output.weight"), h->V, D, EPI_STORE, fa, Wfm<T>("output.weight")));
       return sample_rows(ln->logits.as<float>(), B, h->V, Bp > B, sp, noise, state(), 0, N, out_ids ? out_ids + (size_t)b0 * N : nullptr,
                          ln->cur_tok.as<int32_t>(), trace, nullptr, st, b0, Btot, row_step);
     }
     if (h->cfg.head == VLG_HEAD_ADAPTER2) {
       fa.out = ln->t1.as<T>();
       fa.act = ACT_GELU_TANH;
-      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("vae_latent_adapter2.fc1.weight"), D, D, EPI_STORE, fa));
+      VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("vae_latent_adapter2.fc1.weight"), D, D, EPI_STORE, fa, Wfm<T>("vae_latent_adapter2.fc1.weight")));
       if (h->C <= 16)   // fc2 (N = C) + CFG combine + stores in one launch (3 before)
         return latent_out_fc2<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter2.fc2.weight"), ln->cur_lat.as<float>(),
                                  out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, D, N, sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
@@ -725,7 +755,7 @@ struct Runner {
     // hidden (DiffLoss): cond_embed(norm(x)) is the first op of the head (diffloss.py:227)
     fa.out = ln->d_cemb.as<T>();
     fa.bias = W<T>("diffloss.net.cond_embed.bias");
-    VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("diffloss.net.cond_embed.weight"), h->dW, D, EPI_STORE, fa));
+    VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("diffloss.net.cond_embed.weight"), h->dW, D, EPI_STORE, fa, Wfm<T>("diffloss.net.cond_embed.weight")));
     return diffloss_head(nullptr, sp, noise, out_lat, trace);
   }
 
@@ -951,6 +981,7 @@ struct Runner {
       VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
       FusedGemm f2;
       f2.out = ln->x.as<T>();
+      f2.wfm = fm_on() ? Wfm<T>("vae_latent_adapter.fc2.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
     } else if (h->cfg.model_type == VLG_T2V) {
       VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
@@ -1097,8 +1128,8 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     out_ids = h->outbuf.as<int32_t>();
   Lane* ln = &h->lane;
   VLG_TRY(reserve_lane(h, *ln, B, cfg_on ? 2 * B : B, S));
-  VLG_TRY(ensure_pd_layers(h));
   VLG_TRY(ensure_fm<T>(h));
+  VLG_TRY(ensure_pd_layers(h));
   if (d_mask) VLG_TRY(ln->maskbuf.reserve((size_t)B * Tc * sizeof(float)));
   Runner<T> r{h, ln, ln->st, B, cfg_on ? 2 * B : B, N, S, 0, B, d_mask ? ln->maskbuf.as<float>() : nullptr};
   if (h->cfg.head == VLG_HEAD_HIDDEN) {

@@ -52,6 +52,7 @@ size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 // ---- fused skinny GEMM (gemm_fused.hip): prologue RMSNorm + epilogue residual / RoPE+scatter / SwiGLU / store -------------
 enum FusedEpi { EPI_RESID = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_STORE = 3, EPI_GATED = 4 };
 struct FusedGemm {
+  const void* wfm = nullptr;      // fragment-major copy of the weight (relayout_fragment_major): when set, the kernel streams it instead of w
   const void* norm_w = nullptr;   // PRO: RMSNorm weight [K] (dtype T)
   float eps = 1e-5f;
   void* h = nullptr;              // EPI_RESID / EPI_GATED: residual stream [M,N], updated in place
@@ -249,6 +250,7 @@ struct PdArgs {
   int kchunk;              // K elements of the w2 GEMM staged in LDS at a time (a multiple of 8 k-steps)
   int ns_max;              // upper bound of the attention KV splits
   int ksplit;              // K slices of a wo / w2 output tile (units = D / 16 * ksplit <= workgroups)
+  int fm;                  // the four weight pointers of PdLayer are FRAGMENT-MAJOR copies (relayout_fragment_major): whole-line fragment loads
 #ifdef VLG_PD_PROF
   unsigned long long* prof;   // tools/microbench/pd_lab.hip only: [workgroups][32] wall_clock64 stamps of layer 1
 #endif

@@ -312,15 +312,31 @@ __global__ __launch_bounds__(PD_NTHR) void pd_layers_kernel(PdArgs a) {
   // base (scalar) + ONE per-lane byte offset per K (voff_d / voff_f) + a compile-time j * 512.
   pd_u32x4_t R[PD_NF];
   const unsigned voff_d = (unsigned)((r * D + wave * KS) * ESZ + q * 16), voff_f = (unsigned)((r * F + wave * KS) * ESZ + q * 16);
+  // Fragment-major weights (a.fm, gpt_kernels.h: relayout_fragment_major): the fragment of (tile, K step kk) is the 1 KB block
+  // (tile * K / KS + kk), this lane's 16 bytes at lane * 16 - a wave instruction reads 8 whole cache lines instead of 16 half lines.
+  const bool fm = a.fm != 0;
+  const unsigned voff_fm = (unsigned)wave * 1024u + (unsigned)lane * 16u;
   auto load_set = [&](const void* wv, int K, int row0, int row_step, int kk_lo, int ksw, auto ntw_c) __attribute__((always_inline)) {
     constexpr int NTW = decltype(ntw_c)::value;
-    const unsigned voff = (K == D) ? voff_d : voff_f;
+    // two copies of the loop so that the per-fragment offsets stay compile-time constants in both layouts (a run-time stride made hipcc
+    // keep per-fragment addresses and spill them to scratch - and a scratch reload queues behind the weight stream)
+    if (fm) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const char* tb = reinterpret_cast<const char*>(wv) + ((size_t)(row0 + t * row_step) * K + (size_t)kk_lo * KS) * ESZ;   // wave-uniform
+      for (int t = 0; t < NTW; ++t) {
+        const char* tb = reinterpret_cast<const char*>(wv) + ((size_t)((row0 + t * row_step) >> 4) * (size_t)(K / KS) + (size_t)kk_lo) * 1024;   // wave-uniform
 #pragma unroll
-      for (int j = 0; j < PD_NF / NTW; ++j)
-        if (j < ksw) R[j * NTW + t] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(tb + voff + j * (PD_NW * 64)));
+        for (int j = 0; j < PD_NF / NTW; ++j)
+          if (j < ksw) R[j * NTW + t] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(tb + voff_fm + j * (PD_NW * 1024)));
+      }
+    } else {
+      const unsigned voff = (K == D) ? voff_d : voff_f;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const char* tb = reinterpret_cast<const char*>(wv) + ((size_t)(row0 + t * row_step) * K + (size_t)kk_lo * KS) * ESZ;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < PD_NF / NTW; ++j)
+          if (j < ksw) R[j * NTW + t] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(tb + voff + j * (PD_NW * 64)));
+      }
     }
   };
   // acc[mt][t] += A[rows of mt][this wave's K steps in [kk0, kk1)] . R      (A column of K step kk: (kk - kk0) * KS; kk = kk_lo + wave + 8 j)
