@@ -172,13 +172,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     else
       wbase[hf] = reinterpret_cast<const u32x4_t*>(w + (size_t)(ncol + (r & (NC - 1))) * K) + q;
   }
-  const T* xrow[MT];
+  // A fragment (K block kb, chunk s2) of m-tile mt: abase[mt] + kb * a_kstep + s2 * a_sstep (16-byte units); row-major rows, or the
+  // A-fragment-major matrix (fa.a_fm, gpt_kernels.h afm_index): block (m-tile, K step 4 kb + s2), slot = lane
+  const u32x4_t* abase[MT];
+  const bool afm = fa.a_fm != 0, ofm = fa.o_fm != 0;
+  const int a_sstep = afm ? 64 : 4, a_kstep = afm ? 256 : (int)(KBLK * sizeof(T) / 16);
+  const int o_nks = N * (int)sizeof(T) / 64;   // K steps per row of an A-fragment-major [M, N] result
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int row = m0 + mt * 16 + r;
     row = row < M ? row : M - 1;
-    xrow[mt] = x + (size_t)row * K;
+    if (afm)
+      abase[mt] = reinterpret_cast<const u32x4_t*>(x) + (size_t)((m0 >> 4) + mt) * ((size_t)nkb * 256) + lane;
+    else
+      abase[mt] = reinterpret_cast<const u32x4_t*>(x + (size_t)row * K) + q;
   }
+  auto oidx = [&](int row, int c) -> size_t { return ofm ? afm_index<T>(row, c, o_nks) : (size_t)row * N + c; };
   // Request order = arrival order (vmcnt retires in order): activations (L2) first, then the norm weight, then the weight stream
   // (HBM), then the epilogue operands that do not depend on the GEMM (residual rows; RoPE pair of the current position).  The
   // norm prologue then runs on the activations while the weights are still in flight, and the epilogue never waits on memory.
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
         row = row < M ? row : M - 1;
-        eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + (size_t)row * N + ecol);
+        eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + oidx(row, ecol));
         if constexpr (EPI == EPI_GATED) ecx[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.gate) + (size_t)row * fa.gate_stride + ecol);
       }
     }
@@ -230,9 +239,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       if (kb < nkb) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const u32x4_t* px = reinterpret_cast<const u32x4_t*>(xrow[mt] + (size_t)kb * KBLK) + q;
+          const u32x4_t* px = abase[mt] + (size_t)kb * a_kstep;
 #pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * 4];
+          for (int s2 = 0; s2 < 4; ++s2) a[i][mt][s2] = px[s2 * a_sstep];
         }
       }
     }
@@ -352,21 +361,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     if (row >= M) continue;
     if (NC == 8 && (l2 & 8)) continue;   // mirror lanes
     if constexpr (EPI == EPI_RESID) {
-      DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(s0));
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[mt] + DT<T>::rt(s0));
     } else if constexpr (EPI == EPI_GATED) {
       float v = s0;
       if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
-      DT<T>::st(reinterpret_cast<T*>(fa.h) + (size_t)row * N + col, eres[mt] + DT<T>::rt(ecx[mt] * DT<T>::rt(v)));
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[mt] + DT<T>::rt(ecx[mt] * DT<T>::rt(v)));
     } else if constexpr (EPI == EPI_SWIGLU) {
       const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
-      DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, DT<T>::rt(silu_g(av)) * bv);
+      DT<T>::st(reinterpret_cast<T*>(fa.out) + oidx(row, col), DT<T>::rt(silu_g(av)) * bv);
     } else if constexpr (EPI == EPI_STORE) {
       float v = s0;
       if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
       v = DT<T>::rt(v);
       if (fa.act == ACT_GELU_TANH) v = DT<T>::rt(gelu_g(v));
       if (fa.act == ACT_SILU) v = DT<T>::rt(silu_g(v));
-      if (fa.out) DT<T>::st(reinterpret_cast<T*>(fa.out) + (size_t)row * N + col, v);
+      if (fa.out) DT<T>::st(reinterpret_cast<T*>(fa.out) + oidx(row, col), v);
       if (fa.out_f32) fa.out_f32[(size_t)row * N + col] = v;
     } else {  // EPI_QKV
       const int D = fa.H * fa.hd;

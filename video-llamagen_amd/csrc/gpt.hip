@@ -564,6 +564,7 @@ struct Runner {
   const void* pending = nullptr;       // sessions of text-conditioned models: [rows][D] input rows of slots that start this step
   KvPages pages{};                     // sessions with a block-granular cache: block table of THIS runner's rows
   int pool_blocks = 0;                 //   and the number of blocks in the per-layer pool
+  bool afm = false;                    // this decode step keeps x / attention output / SwiGLU output A-fragment-major (afm_ok)
   size_t kv_lstride() const {
     if (pages.table) return ((size_t)pool_blocks * h->H << pages.shift) * h->hd;
     return (size_t)(kv_rows ? kv_rows : Bp) * h->H * S * h->hd;
@@ -674,6 +675,7 @@ struct Runner {
       fa.H = H;
       fa.hd = hd;
       fa.S = S;
+      fa.a_fm = afm;
       VLG_TRY(norm_gemm(x, W<T>(p + "attention_norm.weight"), W<T>(p + "attention.wqkv.weight"), 3 * D, D, EPI_QKV, fa, Wfm<T>(p + "attention.wqkv.weight")));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
@@ -681,13 +683,15 @@ struct Runner {
         e1 = h->attn_ev[2 * ev_slot + 1];
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, 1, H, hd, S, S - 1, mask, B, h->Tc,
-                           st, e0, e1, row_pos, pages));
+                           st, e0, e1, row_pos, pages, afm ? D * (int)sizeof(T) / 64 : 0));
       FusedGemm fr;
       fr.h = x;
+      fr.a_fm = fr.o_fm = afm;   // A = ao (then g), result = the residual stream x
       fr.wfm = fm_on() ? Wfm<T>(p + "attention.wo.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), M, D, D, false, EPI_RESID, fr, st));
       FusedGemm fs;
       fs.out = ln->g.as<T>();
+      fs.a_fm = fs.o_fm = afm;   // A = x, result = g
       VLG_TRY(norm_gemm(x, W<T>(p + "ffn_norm.weight"), W<T>(p + "feed_forward.w13"), F, D, EPI_SWIGLU, fs, Wfm<T>(p + "feed_forward.w13")));
       fr.wfm = fm_on() ? Wfm<T>(p + "feed_forward.w2.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), M, D, F, false, EPI_RESID, fr, st));
@@ -734,6 +738,7 @@ struct Runner {
   int head_fused(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
     FusedGemm fa;
+    fa.a_fm = afm;   // the residual stream; the head's own results stay row-major
     const T* final_norm = W<T>("norm.weight");
     if (h->cfg.head == VLG_HEAD_LOGITS) {
       fa.out_f32 = ln->logits.as<float>();
@@ -974,12 +979,30 @@ struct Runner {
     return VLG_OK;
   }
 
+  // The activation matrices of a fused decode step (x, attention output, SwiGLU output) A-fragment-major (gpt_kernels.h afm_index)?
+  // Where every consumer is a fused GEMM of this chain: the launch chain (not the persistent step, which hands activations over in its own
+  // format), uniform positions (sessions gather their rows row-major), norms as GEMM prologues (the stand-alone RMSNorm reads rows).
+  bool afm_ok() {
+    static const bool off = getenv("VLG_ACT_FM") != nullptr && atoi(getenv("VLG_ACT_FM")) == 0;   // A/B knob
+    const int D = h->D, F = h->F;
+    if (off || row_pos != nullptr || !fused_decode_ok() || pd_use()) return false;
+    if ((D * (int)sizeof(T)) % 64 != 0 || (F * (int)sizeof(T)) % 64 != 0) return false;
+    bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_fused_ok<T>(Bp, F, D, true, EPI_SWIGLU);
+    if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, true, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_ADAPTER2) ok = ok && gemm_fused_ok<T>(Bp, D, D, true, EPI_STORE);
+    if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, true, EPI_STORE);
+    return ok;
+  }
+
   int decode_step(const vlg_sampling_params& sp, const float* noise, int32_t* out_ids, float* out_lat, float* trace) {
     const int D = h->D;
+    afm = false;
     if (h->cfg.model_type == VLG_T2V && h->fuse_gemm && h->C <= 16 && gemm_fused_ok<T>(Bp, D, D, false, EPI_STORE)) {
       // latent -> adapter.fc1 -> GELU in one launch, fc2 as one fused-GEMM launch (5 launches before)
+      afm = afm_ok();
       VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
       FusedGemm f2;
+      f2.o_fm = afm;
       f2.out = ln->x.as<T>();
       f2.wfm = fm_on() ? Wfm<T>("vae_latent_adapter.fc2.weight") : nullptr;
       VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
@@ -988,7 +1011,9 @@ struct Runner {
       VLG_TRY(linear(ln->latT.as<T>(), "vae_latent_adapter.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
       VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter.fc2.weight", ln->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));
     } else {
-      VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st));
+      afm = afm_ok();
+      VLG_TRY(gather_rows_i32<T>(W<T>("tok_embeddings.weight"), ln->cur_tok.as<int32_t>(), ln->x.as<T>(), Bp, D, h->V, st,
+                                 afm ? D * (int)sizeof(T) / 64 : 0));
     }
     if (fused_decode_ok()) {
       if (pd_use()) {
@@ -1012,6 +1037,7 @@ struct Runner {
     const T* cls_table = h->cfg.model_type == VLG_C2I ? W<T>("cls_embedding.embedding_table.weight") : nullptr;
     VLG_TRY(gather_session_rows<T>(cls_table, h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V, row_cls, ln->cur_tok.as<int32_t>(),
                                    reinterpret_cast<const T*>(pending), ln->x.as<T>(), Bp, D, st));
+    afm = false;
     if (fused_decode_ok()) {
       VLG_TRY(layers_fused());
       return head_fused(sp, nullptr, out_ids, nullptr, nullptr);
@@ -1084,11 +1110,12 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   }
   VLG_TRY(ln.ws.reserve(wsf * sizeof(float)));
   VLG_TRY(ln.attn_ws.reserve(attn_ws_floats(M, H, hd) * sizeof(float)));
-  VLG_TRY(ln.x.reserve((size_t)M * D * e));
+  const size_t Mp = (size_t)std::max(M, round_up(Bp, 16));   // A-fragment-major activations pad their rows to whole 16-row tiles
+  VLG_TRY(ln.x.reserve(Mp * D * e));
   VLG_TRY(ln.xn.reserve((size_t)M * D * e));
   VLG_TRY(ln.q.reserve((size_t)M * D * e));
-  VLG_TRY(ln.ao.reserve((size_t)M * D * e));
-  VLG_TRY(ln.g.reserve((size_t)M * F * e));
+  VLG_TRY(ln.ao.reserve(Mp * D * e));
+  VLG_TRY(ln.g.reserve(Mp * F * e));
   VLG_TRY(ln.t1.reserve((size_t)M * D * e));
   VLG_TRY(ln.hl.reserve((size_t)Bp * D * e));
   if (h->cd > 0) VLG_TRY(ln.condT.reserve((size_t)M * h->cd * e));

@@ -51,8 +51,20 @@ size_t gemm_ws_floats(int M, int N, int K, int elem_size);
 
 // ---- fused skinny GEMM (gemm_fused.hip): prologue RMSNorm + epilogue residual / RoPE+scatter / SwiGLU / store -------------
 enum FusedEpi { EPI_RESID = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_STORE = 3, EPI_GATED = 4 };
+// Activation matrices of the fused decode chain kept A-FRAGMENT-MAJOR ("afm"): element (row, col) of an [M][N] matrix of T sits in the
+// 1 KB block (row / 16, K step = col * sizeof(T) / 64) at 16-byte slot (row % 16) + 16 * (chunk of the step), so that the MFMA A fragment of
+// 16 rows x 64 bytes - the unit every skinny GEMM of the chain loads - is 1 KB contiguous instead of 16 pieces of 64 bytes.  Measured
+// (tools/microbench/act_lab.hip, the 32-row QKV GEMM's load pattern, 240 workgroups, whole-line weights): 8.4 -> 4.4 us per launch.
+// Rows are padded to a multiple of 16.  The same values in another order: results do not change.
+template <typename T>
+__host__ __device__ inline size_t afm_index(int row, int col, int nks) {
+  constexpr int EPS = 64 / (int)sizeof(T), EPC = 16 / (int)sizeof(T);
+  return (((size_t)(row >> 4) * nks + col / EPS) * 64 + (row & 15) + 16 * ((col % EPS) / EPC)) * EPC + (col % EPC);
+}
 struct FusedGemm {
   const void* wfm = nullptr;      // fragment-major copy of the weight (relayout_fragment_major): when set, the kernel streams it instead of w
+  int a_fm = 0;                   // the A operand x [M, K] is A-fragment-major (afm_index)
+  int o_fm = 0;                   // the T-typed result matrix (EPI_RESID / EPI_GATED h, EPI_SWIGLU / EPI_STORE out) [M, N] is A-fragment-major
   const void* norm_w = nullptr;   // PRO: RMSNorm weight [K] (dtype T)
   float eps = 1e-5f;
   void* h = nullptr;              // EPI_RESID / EPI_GATED: residual stream [M,N], updated in place
@@ -127,12 +139,13 @@ int attn_rows(const T* qbuf, T* kcache, T* vcache, T* out, float* partial_ws, co
               int Bp, int Tq, int H, int hd, int S, int max_pos, const float* mask, int Bmask, int Tc,
               hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,  // ev0/ev1 bracket the split-KV kernel
               const int32_t* row_pos = nullptr,    // sessions: batch row b attends keys 0..row_pos[b] (+t)
-              KvPages pages = KvPages{});          // sessions with a block-granular cache
+              KvPages pages = KvPages{},           // sessions with a block-granular cache
+              int out_nks = 0);                    // > 0: `out` [M, H hd] is A-fragment-major (afm_index) with this many 64-byte K steps per row
 size_t attn_ws_floats(int M, int H, int hd);
 
 // embedding gathers -----------------------------------------------------------------------------
 template <typename T>
-int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st);   // gpt.py:354
+int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st, int out_nks = 0);   // gpt.py:354; out_nks > 0: out is A-fragment-major
 template <typename T>
 int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, T* out, int rows, int D, int n_rows, hipStream_t st);  // gpt.py:82 + generate.py:131
 // cond [B,Tc,cd] fp32 (+ uncond [120,cd] for the CFG half) -> T [Bp*Tc, cd]        (generate.py:138-139)

@@ -809,7 +809,8 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
                                                            T* __restrict__ vc, float* __restrict__ ws,
                                                            T* __restrict__ out, const StepState* __restrict__ state,
                                                            int Tq, int H, int S, const float* __restrict__ mask, int Bmask,
-                                                           int Tc, float scale, const int32_t* __restrict__ row_pos, KvPages pg = KvPages{}) {
+                                                           int Tc, float scale, const int32_t* __restrict__ row_pos, KvPages pg = KvPages{},
+                                                           int out_nks = 0) {
   constexpr int RPI = 64 / LPR;  // rows per wave-wide load; U = loads in flight per operand
   constexpr int TILE = RPI * U;
   const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, m = blockIdx.z;
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
       A += sm[wv][2 + d] * e;
     }
     if (nsplit == 1) {
-      DT<T>::st(out + ((size_t)m * H + h) * HD + d, A / L);
+      DT<T>::st(out + (out_nks ? afm_index<T>(m, h * HD + d, out_nks) : ((size_t)m * H + h) * HD + d), A / L);
     } else {
       float* o = ws + (((size_t)m * H + h) * nsplit + split) * (HD + 2);
       o[2 + d] = A;
@@ -941,8 +942,9 @@ __global__ __launch_bounds__(256) void attn_partial_kernel(const T* __restrict__
 // NS: partials requested up front (8 for nsplit <= 8; 16 for the deeper splits of small batches, where this launch is as long as the
 // attention kernel itself if it walks the partials one dependent load at a time)
 template <typename T, int HD, int NS>
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int nsplit) {
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int nsplit, int H, int out_nks) {
   const size_t mh = blockIdx.x;
+  const int om = (int)(mh / H), oc0 = (int)(mh % H) * HD;   // (row, first column) of this head's output in the [M, H hd] matrix
   const float* base = ws + mh * nsplit * (HD + 2);
   constexpr int ND = (HD + 63) / 64;
   if (nsplit <= NS) {
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
       const int d = threadIdx.x + 64 * k;
-      if (d < HD) DT<T>::st(out + mh * HD + d, A[k] / L);
+      if (d < HD) DT<T>::st(out + (out_nks ? afm_index<T>(om, oc0 + d, out_nks) : mh * HD + d), A[k] / L);
     }
     return;
   }
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
   for (int d = threadIdx.x; d < HD; d += 64) {
     float A = 0.f;
     for (int s = 0; s < nsplit; ++s) A += base[(size_t)s * (HD + 2) + 2 + d] * __expf(base[(size_t)s * (HD + 2)] - mref);
-    DT<T>::st(out + mh * HD + d, A / L);
+    DT<T>::st(out + (out_nks ? afm_index<T>(om, oc0 + d, out_nks) : mh * HD + d), A / L);
   }
 }
 
@@ -999,7 +1001,7 @@ size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 
 template <typename T, int HD, int VEC, int LPR>
 static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H,
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                       const int32_t* row_pos, KvPages pages) {
+                       const int32_t* row_pos, KvPages pages, int out_nks) {
   const int M = Bp * Tq;
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
   // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
@@ -1019,22 +1021,22 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
       return VLG_ERR_UNSUPPORTED;
     }
     attn_partial_kernel<T, HD, VEC, LPR, 4, true><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale,
-                                                                                     row_pos, pages);
+                                                                                     row_pos, pages, out_nks);
   } else {
     static const int u_knob = getenv("VLG_ATTN_U") ? atoi(getenv("VLG_ATTN_U")) : 4;
     if (u_knob == 8)
-      attn_partial_kernel<T, HD, VEC, LPR, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 8><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos, KvPages{}, out_nks);
     else if (u_knob == 2)
-      attn_partial_kernel<T, HD, VEC, LPR, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 2><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos, KvPages{}, out_nks);
     else
-      attn_partial_kernel<T, HD, VEC, LPR, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos);
+      attn_partial_kernel<T, HD, VEC, LPR, 4><<<dim3(nsplit, H, M), 256, 0, st>>>(qbuf, kc, vc, ws, out, state, Tq, H, S, mask, Bmask, Tc, scale, row_pos, KvPages{}, out_nks);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (nsplit > 1) {
     if (nsplit <= 8)
-      attn_combine_kernel<T, HD, 8><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+      attn_combine_kernel<T, HD, 8><<<M * H, 64, 0, st>>>(ws, out, nsplit, H, out_nks);
     else
-      attn_combine_kernel<T, HD, 16><<<M * H, 64, 0, st>>>(ws, out, nsplit);
+      attn_combine_kernel<T, HD, 16><<<M * H, 64, 0, st>>>(ws, out, nsplit, H, out_nks);
   }
   return VLG_OK;
 }
@@ -1042,9 +1044,9 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
 template <typename T>
 int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* state, int Bp, int Tq, int H, int hd,
               int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-              const int32_t* row_pos, KvPages pages) {
+              const int32_t* row_pos, KvPages pages, int out_nks) {
 #define VLG_ATTN(HD_, VEC_, LPR_) \
-  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, row_pos, pages)
+  return attn_launch<T, HD_, VEC_, LPR_>(qbuf, kc, vc, out, ws, state, Bp, Tq, H, S, max_pos, mask, Bmask, Tc, st, ev0, ev1, row_pos, pages, out_nks)
   if constexpr (sizeof(T) == 2) {
     if (hd == 64) VLG_ATTN(64, 8, 8);
     if (hd == 128) VLG_ATTN(128, 8, 16);
@@ -1062,24 +1064,24 @@ int attn_rows(const T* qbuf, T* kc, T* vc, T* out, float* ws, const StepState* s
   set_error("attention: unsupported head_dim %d (supported: 32, 64, 96, 100, 128)", hd);
   return VLG_ERR_UNSUPPORTED;
 }
-template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages);
-template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages);
+template int attn_rows<float>(const float*, float*, float*, float*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages, int);
+template int attn_rows<bf16>(const bf16*, bf16*, bf16*, bf16*, float*, const StepState*, int, int, int, int, int, int, const float*, int, int, hipStream_t, hipEvent_t, hipEvent_t, const int32_t*, KvPages, int);
 
 // ------------------------------------------------------------------------------------------------
 // gathers and small glue kernels
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ table, const I* __restrict__ idx, int n_idx,
-                                                          int null_id, T* __restrict__ out, int rows, int D, int n_rows) {
+                                                          int null_id, T* __restrict__ out, int rows, int D, int n_rows, int out_nks = 0) {
   const int r = blockIdx.x;
   long long id = r < n_idx ? (long long)idx[r] : (long long)null_id;
   id = id < 0 ? 0 : (id >= n_rows ? n_rows - 1 : id);   // never fault on a bad id
   const T* src = table + (size_t)id * D;
-  for (int i = threadIdx.x; i < D; i += 256) out[(size_t)r * D + i] = src[i];
+  for (int i = threadIdx.x; i < D; i += 256) out[out_nks ? afm_index<T>(r, i, out_nks) : (size_t)r * D + i] = src[i];
 }
 template <typename T>
-int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st) {
-  gather_rows_kernel<T, int32_t><<<rows, 256, 0, st>>>(table, idx, rows, 0, out, rows, D, n_rows);
+int gather_rows_i32(const T* table, const int32_t* idx, T* out, int rows, int D, int n_rows, hipStream_t st, int out_nks) {
+  gather_rows_kernel<T, int32_t><<<rows, 256, 0, st>>>(table, idx, rows, 0, out, rows, D, n_rows, out_nks);
   return VLG_OK;
 }
 template <typename T>
@@ -1087,8 +1089,8 @@ int gather_rows_i64(const T* table, const int64_t* idx, int n_idx, int null_id, 
   gather_rows_kernel<T, int64_t><<<rows, 256, 0, st>>>(table, idx, n_idx, null_id, out, rows, D, n_rows);
   return VLG_OK;
 }
-template int gather_rows_i32<float>(const float*, const int32_t*, float*, int, int, int, hipStream_t);
-template int gather_rows_i32<bf16>(const bf16*, const int32_t*, bf16*, int, int, int, hipStream_t);
+template int gather_rows_i32<float>(const float*, const int32_t*, float*, int, int, int, hipStream_t, int);
+template int gather_rows_i32<bf16>(const bf16*, const int32_t*, bf16*, int, int, int, hipStream_t, int);
 template int gather_rows_i64<float>(const float*, const int64_t*, int, int, float*, int, int, int, hipStream_t);
 template int gather_rows_i64<bf16>(const bf16*, const int64_t*, int, int, bf16*, int, int, int, hipStream_t);
 
