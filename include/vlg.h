@@ -138,7 +138,9 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "dl_persist" (1: DiffLoss sampler as one persistent launch per
  * token), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts; "pd_rows" = row
- * cap replacing the measured rule), "debug_pos_offset" (0; benchmarks: decode starts `offset` positions after the condition, over zeroed
+ * cap replacing the measured rule), "weights_fm" (1) / "act_fm" (1): the decode GEMMs read fragment-major copies of
+ * the Linear weights (one MFMA B fragment = 1 KB contiguous, built at the first call after a load; twice the weight memory for those
+ * tensors) and the fused chain keeps its activations A-fragment-major - whole-cache-line requests, bit-identical results; "debug_pos_offset" (0; benchmarks: decode starts `offset` positions after the condition, over zeroed
  * cache rows - the cost of a late-context step without generating up to it), "kv_block" / "kv_pool_blocks" (sessions, see above).  Unknown keys return VLG_ERR_BAD_ARG.  (The measured-slower variants
  * of rounds 1-2 - batch lanes, fuse_qkv, attn_inlaunch, splitk_inlaunch, gemm_lds - were removed in round 3; DESIGN.md section 5
  * keeps their measurements.)                                                                                         */

@@ -810,3 +810,39 @@ def test_debug_pos_offset_decodes_late_context():
         V.generate_t2v(m, c, 6, mk)
     m.debug_pos_offset = 0
     assert torch.equal(V.generate_t2v(m, c, 6, mk), base)
+
+
+def test_fragment_major_layouts_are_bit_identical():
+    """Options weights_fm / act_fm only change WHERE the bytes of the weights and of the fused chain's activations sit (one MFMA fragment =
+    1 KB contiguous, include/vlg.h): same fragment contents, same MFMA order, same reductions - so every combination must reproduce
+    the row-major result bit for bit.  BASELINE config-4 widths on a 2-layer stack at 32 rows (fused launch chain) and 4 rows (persistent
+    step), and a token model under guidance (logits head, sampler)."""
+    import video_llamagen_amd as V
+    m = V.Transformer(V.ModelArgs(dim=1280, n_layer=2, n_head=20, block_size=1024, cls_token_num=120, model_type="t2v", vae_embed_dim=8,
+                                  num_frames=17, t_downsample_size=4)).to("cuda", torch.bfloat16)
+    m.init_random_weights(seed=3)
+    g = torch.Generator().manual_seed(0)
+    cond = torch.randn(32, 120, 2048, generator=g) * 0.1
+    mask = torch.zeros(32, 120)
+    for b in range(32):
+        mask[b, 120 - (8 + 3 * b):] = 1
+    cond = cond * mask[:, :, None]
+    for rows in (32, 24, 4):
+        ref = None
+        for wfm, afm in ((False, False), (True, False), (True, True), (False, True)):
+            m.weights_fm, m.act_fm = wfm, afm
+            out = V.generate_t2v(m, cond[:rows], 24, mask[:rows])
+            assert torch.isfinite(out).all()
+            if ref is None:
+                ref = out
+            assert torch.equal(out, ref), (rows, wfm, afm)
+    t = V.Transformer(V.ModelArgs(dim=1024, n_layer=2, n_head=16, block_size=576, cls_token_num=1, model_type="c2i")).to("cuda", torch.bfloat16)
+    t.init_random_weights(seed=1)
+    cls = torch.randint(0, 1000, (12,), generator=torch.Generator().manual_seed(0)).to("cuda")
+    ref = None
+    for wfm, afm in ((False, False), (True, True)):
+        t.weights_fm, t.act_fm = wfm, afm
+        ids, tr = V.generate(t, cls, 16, cfg_scale=4.0, sample_logits=False, return_trace=True)
+        if ref is None:
+            ref = (ids, tr)
+        assert torch.equal(ids, ref[0]) and torch.equal(tr, ref[1])

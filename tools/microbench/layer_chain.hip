@@ -45,6 +45,24 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* p, size_t n1
   if (acc == 0x12345678u) *sink = acc;
 }
 
+// fragment-major copy of a [N][K] bf16 matrix (gpt_kernels.h: relayout_fragment_major)
+__global__ __launch_bounds__(256) void lab_fm_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, long long chunks, int nks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= chunks) return;
+  const int l = (int)(i & 63);
+  const long long blk = i >> 6;
+  const long long t = blk / nks;
+  const int s = (int)(blk - t * nks);
+  out[i] = w[(t * 16 + (l & 15)) * (long long)(nks * 4) + s * 4 + (l >> 4)];
+}
+static bf16* fm_copy(const bf16* w, int N, int K) {
+  bf16* o;
+  CK(hipMalloc(&o, (size_t)N * K * 2));
+  const long long chunks = (long long)N * K / 8;
+  lab_fm_kernel<<<dim3((unsigned)((chunks + 255) / 256)), 256>>>((const uint4*)w, (uint4*)o, chunks, K / 32);
+  return o;
+}
+
 static bf16* alloc_fill(size_t n, uint32_t seed, float scale) {
   bf16* p;
   CK(hipMalloc(&p, n * 2));
@@ -58,6 +76,7 @@ int main(int argc, char** argv) {
   const int reps = 30;
   const bool static_a = argc > 2 && atoi(argv[2]) == 1;   // experiment: prologue kernels read a never-written activation buffer
   const int prefetch = argc > 3 ? atoi(argv[3]) : 0;      // 1: read each layer's weights right before its four kernels (warm MALL / L2)
+  const int fmode = argc > 4 ? atoi(argv[4]) : 2;         // 0: row-major everything, 1: fragment-major weights, 2: + A-fragment-major activations
   unsigned* sink;
   CK(hipMalloc(&sink, 4));
   std::vector<bf16*> wqkv(L), wo(L), w13(L), w2(L), nw1(L), nw2(L);
@@ -66,6 +85,13 @@ int main(int argc, char** argv) {
     wo[l] = alloc_fill((size_t)D * D, 11 * l + 2, 0.04f);
     w13[l] = alloc_fill((size_t)2 * F * D, 11 * l + 3, 0.04f);
     w2[l] = alloc_fill((size_t)D * F, 11 * l + 4, 0.04f);
+    if (fmode >= 1) {
+      bf16* t;
+      t = fm_copy(wqkv[l], 3 * D, D); CK(hipDeviceSynchronize()); CK(hipFree(wqkv[l])); wqkv[l] = t;
+      t = fm_copy(wo[l], D, D); CK(hipDeviceSynchronize()); CK(hipFree(wo[l])); wo[l] = t;
+      t = fm_copy(w13[l], 2 * F, D); CK(hipDeviceSynchronize()); CK(hipFree(w13[l])); w13[l] = t;
+      t = fm_copy(w2[l], D, F); CK(hipDeviceSynchronize()); CK(hipFree(w2[l])); w2[l] = t;
+    }
     nw1[l] = alloc_fill(D, 11 * l + 5, 2.0f);
     nw2[l] = alloc_fill(D, 11 * l + 6, 2.0f);
   }
@@ -104,18 +130,26 @@ int main(int argc, char** argv) {
       fa.norm_w = nw1[l];
       fa.qbuf = q; fa.kc = kc; fa.vc = vc; fa.freqs = freqs; fa.state = state; fa.Tq = 1; fa.H = H; fa.hd = hd; fa.S = S;
       fa.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
+      if (fmode >= 1) fa.wfm = wqkv[l];
+      fa.a_fm = fmode >= 2;
       if (gemm_fused<bf16>(static_a ? x0 : x, wqkv[l], M, 3 * D, D, true, EPI_QKV, fa, st)) { fprintf(stderr, "qkv fail\n"); exit(1); }
       FusedGemm fb;
       fb.h = x;
+      if (fmode >= 1) fb.wfm = wo[l];
+      fb.a_fm = fb.o_fm = fmode >= 2;
       fb.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
       if (gemm_fused<bf16>(ao, wo[l], M, D, D, false, EPI_RESID, fb, st)) exit(1);
       FusedGemm fc;
       fc.norm_w = nw2[l];
       fc.out = g;
+      if (fmode >= 1) fc.wfm = w13[l];
+      fc.a_fm = fc.o_fm = fmode >= 2;
       fc.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
       if (gemm_fused<bf16>(static_a ? x0 : x, w13[l], M, F, D, true, EPI_SWIGLU, fc, st)) exit(1);
       FusedGemm fd;
       fd.h = x;
+      if (fmode >= 1) fd.wfm = w2[l];
+      fd.a_fm = fd.o_fm = fmode >= 2;
       fd.trace = tr ? trace + (size_t)k * MAXG * 4 : nullptr; ++k;
       if (gemm_fused<bf16>(g, w2[l], M, D, F, false, EPI_RESID, fd, st)) exit(1);
     }

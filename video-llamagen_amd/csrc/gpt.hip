@@ -68,6 +68,8 @@ struct vlg_gpt {
   int spin_max = 0;                  // option debug_spin_max (0 = default bound)
   bool pdecode = true;               // decode layers as one persistent launch per step (pdecode.hip) where the shape allows
   int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured rule of pd_use())
+  bool weights_fm = true;            // stream the fragment-major weight copies (option "weights_fm"; results are bit-identical either way)
+  bool act_fm = true;                // keep the fused decode chain's activations A-fragment-major (option "act_fm"; bit-identical either way)
   int pos_offset = 0;                // benchmarks ("debug_pos_offset"): decode as if this many tokens had already been generated (zeroed cache rows)
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool pd_fm = false;                // ... which are the fragment-major copies
@@ -421,6 +423,14 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->pos_offset = (int)value;
     return VLG_OK;
   }
+  if (!strcmp(key, "weights_fm")) {
+    h->weights_fm = value != 0;
+    return VLG_OK;
+  }
+  if (!strcmp(key, "act_fm")) {
+    h->act_fm = value != 0;
+    return VLG_OK;
+  }
   if (!strcmp(key, "pd_rows")) {
     VLG_CHECK(value >= 0 && value <= 32, VLG_ERR_BAD_ARG, "pd_rows must be in 0..32");
     h->pd_rows = (int)value;
@@ -527,7 +537,7 @@ int ensure_fm(vlg_gpt* h) {
 // any stream capture)
 int ensure_pd_layers(vlg_gpt* h) {   // after ensure_fm: the table points at the fragment-major copies when every layer has them
   static const bool fm_off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;
-  bool fm = !fm_off;
+  bool fm = !fm_off && h->weights_fm;
   for (int l = 0; l < h->L && fm; ++l) {
     const std::string p = "layers." + std::to_string(l) + ".";
     for (const char* nm : {"attention.wqkv.weight", "attention.wo.weight", "feed_forward.w13", "feed_forward.w2.weight"}) fm = fm && h->Wfm(p + nm) != nullptr;
@@ -599,7 +609,7 @@ struct Runner {
       int sp = 1;
       T* kc = ln->kcache.as<T>() + lstride * l + kv_off();
       T* vc = ln->vcache.as<T>() + lstride * l + kv_off();
-      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st, Wfm<T>(p + "attention.wqkv.weight")));
+      VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "attention.wqkv.weight"), ws, M, 3 * D, D, &sp, st, fm_on() ? Wfm<T>(p + "attention.wqkv.weight") : nullptr));
       VLG_TRY(qkv_rope_scatter<T>(ws, sp, ln->q.as<T>(), kc, vc, h->freqs.as<float>(), state(), M, Tq, H, hd, S, st, row_pos, pages));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (l == 0 && ev_slot >= 0) {
@@ -608,13 +618,13 @@ struct Runner {
       }
       VLG_TRY(attn_rows<T>(ln->q.as<T>(), kc, vc, ln->ao.as<T>(), ln->attn_ws.as<float>(), state(), Bp, Tq, H, hd, S, max_pos, mask, B,
                            h->Tc, st, e0, e1, row_pos, pages));
-      VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st, Wfm<T>(p + "attention.wo.weight")));
+      VLG_TRY(gemm_slabs<T>(ln->ao.as<T>(), W<T>(p + "attention.wo.weight"), ws, M, D, D, &sp, st, fm_on() ? Wfm<T>(p + "attention.wo.weight") : nullptr));
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(p + "ffn_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
       if (!h->fuse_swiglu || !gemm_swiglu<T>(xn, W<T>(p + "feed_forward.w13"), ln->g.as<T>(), M, F, D, st)) {
-        VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st, Wfm<T>(p + "feed_forward.w13")));
+        VLG_TRY(gemm_slabs<T>(xn, W<T>(p + "feed_forward.w13"), ws, M, 2 * F, D, &sp, st, fm_on() ? Wfm<T>(p + "feed_forward.w13") : nullptr));
         VLG_TRY(reduce_silu_mul<T>(ws, sp, ln->g.as<T>(), M, F, st));
       }
-      VLG_TRY(gemm_slabs<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st, Wfm<T>(p + "feed_forward.w2.weight")));
+      VLG_TRY(gemm_slabs<T>(ln->g.as<T>(), W<T>(p + "feed_forward.w2.weight"), ws, M, D, F, &sp, st, fm_on() ? Wfm<T>(p + "feed_forward.w2.weight") : nullptr));
       const std::string nxt = (l + 1 < h->L) ? "layers." + std::to_string(l + 1) + ".attention_norm.weight" : std::string("norm.weight");
       VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(nxt), xn, M, D, h->cfg.norm_eps, st));
     }
@@ -636,9 +646,9 @@ struct Runner {
     if (h->cfg.head == VLG_HEAD_HIDDEN) ok = ok && gemm_fused_ok<T>(Bp, h->dW, D, pro, EPI_STORE);
     return ok;
   }
-  static bool fm_on() {   // A/B knob: VLG_GEMM_FM=0 streams the row-major weights everywhere
+  bool fm_on() const {   // A/B knobs: option "weights_fm" = 0 / VLG_GEMM_FM=0 stream the row-major weights everywhere
     static const bool off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;
-    return !off;
+    return !off && h->weights_fm;
   }
   // y = epilogue(RMSNorm(x; norm_w) @ w^T): one launch with the norm as the GEMM's prologue, or norm + GEMM where the prologue does not
   // cover K (same rounding points: the explicit kernel is the slab path's, xn rounded to T either way)
@@ -985,7 +995,7 @@ struct Runner {
   bool afm_ok() {
     static const bool off = getenv("VLG_ACT_FM") != nullptr && atoi(getenv("VLG_ACT_FM")) == 0;   // A/B knob
     const int D = h->D, F = h->F;
-    if (off || row_pos != nullptr || !fused_decode_ok() || pd_use()) return false;
+    if (off || !h->act_fm || row_pos != nullptr || !fused_decode_ok() || pd_use()) return false;
     if ((D * (int)sizeof(T)) % 64 != 0 || (F * (int)sizeof(T)) % 64 != 0) return false;
     bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_fused_ok<T>(Bp, F, D, true, EPI_SWIGLU);
     if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, true, EPI_STORE);
@@ -1228,7 +1238,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
-                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset};
+                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset, (uint64_t)((h->weights_fm ? 1 : 0) | (h->act_fm ? 2 : 0))};
       {
         const auto pk = ln->ptr_key();
         key.insert(key.end(), pk.begin(), pk.end());

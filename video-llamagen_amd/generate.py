@@ -66,6 +66,8 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(1 if getattr(model, "dl_persist", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"pdecode", C.c_int64(1 if getattr(model, "pdecode", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_pos_offset", C.c_int64(int(getattr(model, "debug_pos_offset", 0)))))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"weights_fm", C.c_int64(1 if getattr(model, "weights_fm", True) else 0)))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"act_fm", C.c_int64(1 if getattr(model, "act_fm", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"pd_rows", C.c_int64(int(getattr(model, "pd_rows", 0)))))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_spin_max", C.c_int64(int(getattr(model, "debug_spin_max", 0)))))
         if latent and model._head_code() == L.VLG_HEAD_HIDDEN:

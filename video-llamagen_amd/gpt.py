@@ -116,6 +116,8 @@ class Transformer:
         self.debug_spin_max = 0   # tests: spin bound of the persistent kernels' in-launch waits (0 = default)
         self.pdecode = True      # decode: all layers of a step as one persistent launch (csrc/pdecode.hip) where the shape allows (<= 16 rows)
         self.debug_pos_offset = 0  # benchmarks: decode as if this many tokens had already been generated (zeroed cache rows): late-context timing
+        self.weights_fm = True   # decode GEMMs stream the fragment-major weight copies (one MFMA B fragment = 1 KB contiguous); bit-identical results
+        self.act_fm = True       # the fused decode chain keeps its activations A-fragment-major; bit-identical results
         self.pd_rows = 0         # ... up to this many cache rows (0 = the library's measured default)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
 
