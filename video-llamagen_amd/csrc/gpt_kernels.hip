@@ -454,6 +454,7 @@ static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& 
       if (N % (64 * ntw) != 0) continue;
       const int tiles = N / (64 * ntw);
       int sp = 256 / tiles;                    // one round: a compute unit with two workgroups would take twice as long as the others
+      // (one slice more where the round is under-filled - GPT-3B w13: 68 x 4 = 272 instead of 204 workgroups - measured slower: 2.32 vs 2.26 s)
       if (sp > nkb / 2) sp = nkb / 2;
       if (sp > gemm_max_splits()) sp = gemm_max_splits();   // the reduce_* kernels merge up to 8 slabs
       if (sp < 1) sp = 1;

@@ -121,23 +121,60 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
       for (int shift = 24; shift >= 0; shift -= 8) {
         if (t < 256) sm.hist[t] = 0;
         __syncthreads();
+        // Histogram of the digit at `shift` over the keys that still match the prefix.  In the first passes nearly all keys of a wave share
+        // one digit (sign + exponent): the lanes that agree with the wave's first active lane are counted with one ballot and ONE atomic,
+        // only the others go to the LDS atomic unit one by one (64 same-address atomics per wave instruction otherwise).
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-          if (t + i * NT < V) {
-            const uint32_t key = fkey(x[i]);
-            if ((key & pmask) == prefix) atomicAdd(&sm.hist[(key >> shift) & 255u], 1u);
+          const uint32_t key = fkey(x[i]);
+          const bool act = (t + i * NT < V) && ((key & pmask) == prefix);
+          const uint32_t dig = (key >> shift) & 255u;
+          const unsigned long long am = __ballot(act);
+          if (am != 0ull) {
+            const int first = __ffsll((long long)am) - 1;
+            const uint32_t d0 = (uint32_t)__shfl((int)dig, first);
+            const unsigned long long same = __ballot(act && dig == d0);
+            if ((int)(threadIdx.x & 63) == first) atomicAdd(&sm.hist[d0], (uint32_t)__popcll(same));
+            if (act && dig != d0) atomicAdd(&sm.hist[dig], 1u);
           }
         }
         __syncthreads();
-        if (t == 0) {
-          int cnt = 0, d = 255;
-          for (; d > 0; --d) {
-            const int hcount = (int)sm.hist[d];
-            if (cnt + hcount >= kk) break;
-            cnt += hcount;
+        // digit = the first d (from 255 down) with count(digits > d) + hist[d] >= kk, else 0; by wave 0: lane l owns digits 255 - 4l .. 252 - 4l,
+        // an inclusive scan over the lanes gives every lane the count of all larger digits (the serial form walked 256 dependent LDS reads)
+        if (t < 64) {
+          int c[4], own = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c[j] = (int)sm.hist[255 - 4 * t - j];
+            own += c[j];
           }
-          sm.bcast[0] = (uint32_t)d;
-          sm.bcast[1] = (uint32_t)(kk - cnt);
+          int incl = own;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (t >= o) incl += up;
+          }
+          int above = incl - own;     // keys whose digit is larger than every digit of this lane
+          int dsel = -1, csel = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int d = 255 - 4 * t - j;
+            if (dsel < 0 && d > 0 && above + c[j] >= kk) {
+              dsel = d;
+              csel = above;
+            }
+            above += c[j];
+          }
+          const unsigned long long hit = __ballot(dsel >= 0);
+          if (hit != 0ull) {
+            if (t == __ffsll((long long)hit) - 1) {
+              sm.bcast[0] = (uint32_t)dsel;
+              sm.bcast[1] = (uint32_t)(kk - csel);
+            }
+          } else if (t == 63) {          // no digit above 0 reaches kk: digit 0, everything above it counted (`above` now includes digit 0's lane mates 3..1)
+            sm.bcast[0] = 0u;
+            sm.bcast[1] = (uint32_t)(kk - (above - c[3]));
+          }
         }
         __syncthreads();
         prefix |= sm.bcast[0] << shift;
