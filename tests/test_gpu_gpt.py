@@ -846,3 +846,19 @@ def test_fragment_major_layouts_are_bit_identical():
         if ref is None:
             ref = (ids, tr)
         assert torch.equal(ids, ref[0]) and torch.equal(tr, ref[1])
+
+
+def test_fragment_major_copies_follow_a_weight_reload():
+    """The fragment-major weight copies are built lazily after a load and must be rebuilt when tensors are loaded again (a stale copy
+    would silently serve the old weights on the decode path while prefill reads the new ones)."""
+    import video_llamagen_amd as V
+    args = dict(dim=256, n_layer=2, n_head=4, block_size=64, cls_token_num=1, model_type="c2i")
+    cls = torch.tensor([3, 7, 11, 500], device="cuda")
+    a = V.Transformer(V.ModelArgs(**args)).to("cuda", torch.bfloat16)
+    a.init_random_weights(seed=1)
+    ids1 = V.generate(a, cls, 24, cfg_scale=2.0, sample_logits=False)
+    a.init_random_weights(seed=2)                      # reload every tensor of the same handle
+    ids2 = V.generate(a, cls, 24, cfg_scale=2.0, sample_logits=False)
+    b = V.Transformer(V.ModelArgs(**args)).to("cuda", torch.bfloat16)
+    b.init_random_weights(seed=2)
+    assert torch.equal(ids2, V.generate(b, cls, 24, cfg_scale=2.0, sample_logits=False)) and not torch.equal(ids1, ids2)
