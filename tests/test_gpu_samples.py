@@ -201,6 +201,58 @@ def test_t2i_sessions_vs_reference_golden(golden):
         eng.add_request("x", None, sp, prompt_token_ids=[3])           # a text-conditioned engine takes features, not class ids
 
 
+def test_kv_block_growth_and_preemption_vs_reference_golden(golden):
+    """kv_policy "grow" (vLLM's scheduler policy behind autoregressive/serve/: blocks appended as a sequence grows, the youngest running
+    sequence preempted by recomputation when the pool runs dry): requests are admitted with one block, grow, get preempted and start
+    over - and every request's greedy ids still equal the REFERENCE's generate().  17 positions = 3 blocks of 8 per row."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt
+    g = golden("gpt")
+    cfg = cases.TINY_C2I
+    m, _ = product_gpt(cfg, torch.float32)
+    labels = [int(c) for c in cases.class_ids(3, cfg["num_classes"])]
+    N, null = cfg["block_size"], cfg["num_classes"]
+
+    def run(engine, with_null):
+        for i, c in enumerate(labels):
+            engine.add_request(str(i), None, V.SamplingParams(temperature=0.0, max_tokens=N), [c])
+        for i in range(3 if with_null else 0):
+            engine.add_request(str(3 + i), None, V.SamplingParams(temperature=0.0, max_tokens=N), [null])
+        outs, steps = {}, 0
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = o.outputs[0].token_ids
+            steps += 1
+            assert steps < 400
+        return [np.array(outs[i]) for i in range(3 + (3 if with_null else 0))]
+
+    # scratch + 5 blocks, three slots: all three start on one block each (the "reserve" policy would admit ONE: 3 blocks each), two more
+    # blocks are handed out as they grow, then the pool is dry: the youngest goes back to the queue, later the next one
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=3, max_tokens=N, kv_block_size=8, num_kv_blocks=6, kv_policy="grow")
+    out = run(e, False)
+    assert e.preempted >= 1 and all((out[i] == g["c2i_fp32_greedy_ids"][i]).all() for i in range(3))
+    # under guidance every slot owns two rows (conditional + null-class partner): 6 blocks per request, pool of 10 + scratch
+    e = V.ContinuousLLMEngine(m, cfg_scale=2.5, cfg_interval=6, max_num_seqs=6, max_tokens=N, kv_block_size=8, num_kv_blocks=11, kv_policy="grow")
+    out = run(e, True)
+    assert e.preempted >= 1
+    for i in range(3):
+        assert (out[i] == g["c2i_fp32_cfg_ids"][i]).all() and (out[3 + i] == out[i]).all()      # null-class members repeat their partner's tokens
+    # a pool that holds everything: the policy never preempts and needs no more iterations than "reserve"
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=3, max_tokens=N, kv_block_size=8, num_kv_blocks=10, kv_policy="grow")
+    out = run(e, False)
+    assert e.preempted == 0 and e.steps_run == N and all((out[i] == g["c2i_fp32_greedy_ids"][i]).all() for i in range(3))
+    # one request alone must fit: 2 blocks + scratch cannot hold 3 blocks
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=2, max_tokens=N, kv_block_size=8, num_kv_blocks=3, kv_policy="grow")
+    e.add_request("0", None, V.SamplingParams(temperature=0.0, max_tokens=N), [labels[0]])
+    with pytest.raises(ValueError):
+        while e.has_unfinished_requests():
+            e.step()
+    e.close()
+    with pytest.raises(ValueError):
+        V.ContinuousLLMEngine(m, kv_block_size=8, kv_policy="swap")
+
+
 def test_block_granular_kv_sessions_vs_reference_golden(golden):
     """The iteration-level engine on a block-granular KV cache (vlg_gpt_session_reserve / release, paged attention + paged KV append):
     ids equal the REFERENCE's generate().  Pools are sized so that (a) blocks are handed out in scrambled order and reused by later

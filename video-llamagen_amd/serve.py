@@ -80,6 +80,7 @@ class _Request:
     arrival: float
     prompt_embeds: Optional[torch.Tensor] = None     # text-conditioned models: [cls_token_num, caption_dim] features (already * mask)
     emb_mask: Optional[torch.Tensor] = None          # [cls_token_num], 1 = valid, left-padded
+    order: int = 0                                   # arrival order inside an engine (preemption picks the youngest running request)
 
 
 class Scheduler:
@@ -180,10 +181,16 @@ class ContinuousLLMEngine:
     a session share the sampling parameters of the first one except `max_tokens` (<= the session's)."""
 
     def __init__(self, model, cfg_scale=1.0, cfg_interval=-1, max_num_seqs=256, seed=0, max_tokens=None, kv_block_size=0,
-                 num_kv_blocks=0):
-        """kv_block_size > 0: block-granular KV cache (vLLM's `block_size` / `num_gpu_blocks`): every request reserves blocks for ITS
-        length at admission and returns them when it finishes; a request the pool cannot cover yet stays queued.  num_kv_blocks = 0
-        sizes the pool for every slot at full length."""
+                 num_kv_blocks=0, kv_policy="reserve"):
+        """kv_block_size > 0: block-granular KV cache (vLLM's `block_size` / `num_gpu_blocks`); num_kv_blocks = 0 sizes the pool for
+        every slot at full length.  kv_policy:
+          "reserve"  every request reserves blocks for ITS whole length at admission and returns them when it finishes; a request the
+                     pool cannot cover yet stays queued (no running request is ever disturbed);
+          "grow"     vLLM's scheduler policy (the block manager behind autoregressive/serve/: blocks are appended as a sequence grows,
+                     and when the pool runs dry the most recently arrived running sequence is PREEMPTED by recomputation): a request is
+                     admitted with the blocks of its condition + first token, grows block by block, and on exhaustion the youngest
+                     running request gives its blocks back and returns to the head of the queue to start over.  More requests in flight
+                     for the same pool; greedy results are unchanged, sampled ones depend on the slot a request ends up in."""
         import ctypes as C
         from . import _lib as L
         self._C, self._L = C, L
@@ -195,6 +202,11 @@ class ContinuousLLMEngine:
         self.slots_n = max(1, max_num_seqs // 2 if (self.cfg and not self.text) else max_num_seqs)
         self.max_tokens = max_tokens
         self.kv_block_size, self.num_kv_blocks = int(kv_block_size), int(num_kv_blocks)
+        if kv_policy not in ("reserve", "grow"):
+            raise ValueError("kv_policy must be 'reserve' or 'grow'")
+        self.kv_policy = kv_policy if self.kv_block_size > 0 else "reserve"
+        self._arrivals = 0
+        self.preempted = 0                            # running requests sent back to the queue because the pool ran dry (kv_policy "grow")
         self.deferred = 0                             # admissions postponed because the KV pool was full
         self.waiting = collections.deque()
         self.pending_null = collections.deque()      # null-class partner requests (reported with their partner's tokens)
@@ -212,11 +224,13 @@ class ContinuousLLMEngine:
             want = (self.model.cls_token_num, self.model.config.caption_dim)
             if tuple(prompt_embeds.shape) != want:
                 raise ValueError("prompt_embeds must be %s, got %s" % (want, tuple(prompt_embeds.shape)))
-            self.waiting.append(_Request(str(request_id), [], sampling_params or SamplingParams(), time.time(), prompt_embeds, emb_mask))
+            self._arrivals += 1
+            self.waiting.append(_Request(str(request_id), [], sampling_params or SamplingParams(), time.time(), prompt_embeds, emb_mask, self._arrivals))
             return
         if prompt_token_ids is None or len(prompt_token_ids) != 1:
             raise ValueError("class-conditional prompts hold exactly one class id")
-        r = _Request(str(request_id), list(prompt_token_ids), sampling_params or SamplingParams(), time.time())
+        self._arrivals += 1
+        r = _Request(str(request_id), list(prompt_token_ids), sampling_params or SamplingParams(), time.time(), order=self._arrivals)
         if self.cfg and r.prompt_token_ids[0] == self.null_token:
             self.pending_null.append(r)
         else:
@@ -247,14 +261,41 @@ class ContinuousLLMEngine:
         self._L.check(self._L.lib().vlg_gpt_session_free_blocks(self.model._handle, self._C.byref(n), self._C.byref(bs)))
         return n.value
 
-    def _reserve(self, slot, r):
-        """True when the slot now owns KV blocks for the request; False = pool full, try again after a request has finished."""
-        rc = self._L.lib().vlg_gpt_session_reserve(self.model._handle, slot, int(r.params.max_tokens))
+    def _reserve(self, slot, r, tokens=None):
+        """True when the slot now owns KV blocks for `tokens` tokens of the request (default: all of them); False = pool full."""
+        n = int(r.params.max_tokens) if tokens is None else max(1, min(int(tokens), int(r.params.max_tokens)))
+        rc = self._L.lib().vlg_gpt_session_reserve(self.model._handle, slot, n)
         if rc == self._L.VLG_ERR_OOM:
-            self.deferred += 1
             return False
         self._L.check(rc)
         return True
+
+    def _preempt(self, slot):
+        """vLLM's preemption by recomputation: the request leaves its slot, its blocks return to the pool, and it goes back to the HEAD of
+        the queue (with its null-class partner) to start over when blocks are free again."""
+        r, _, partner = self.slots[slot]
+        self._L.check(self._L.lib().vlg_gpt_session_release(self.model._handle, slot))
+        self.slots[slot] = None
+        self.waiting.appendleft(r)
+        if partner is not None:
+            self.pending_null.appendleft(partner)
+        self.preempted += 1
+
+    def _grow(self):
+        """kv_policy "grow": before an iteration every running request must own the block its next position falls into.  Oldest requests
+        first; when the pool cannot serve one, the YOUNGEST running request is preempted (possibly the asker itself).  Returns True when
+        something was preempted (no admission in this iteration then: the freed blocks belong to the survivors)."""
+        order = sorted((i for i, s in enumerate(self.slots) if s is not None), key=lambda i: self.slots[i][0].order)
+        hit = False
+        for i in order:
+            while self.slots[i] is not None and not self._reserve(i, self.slots[i][0], self.slots[i][1] + 1):
+                running = [j for j, s in enumerate(self.slots) if s is not None]
+                victim = max(running, key=lambda j: self.slots[j][0].order)
+                if len(running) == 1:
+                    raise ValueError("request %s does not fit the KV pool even when it runs alone" % self.slots[i][0].request_id)
+                self._preempt(victim)
+                hit = True
+        return hit
 
     def close(self):
         if self._open:
@@ -268,7 +309,9 @@ class ContinuousLLMEngine:
                 return []
             self._begin(self.waiting[0].params)
         row_class = (C.c_int32 * self.slots_n)()
-        blocked = False                                             # the head of the queue waits for KV blocks: nobody overtakes it (FIFO),
+        grow = self.kv_policy == "grow"
+        blocked = self._grow() if grow else False                   # growth first; after a preemption nobody is admitted in this iteration
+        # the head of the queue waits for KV blocks: nobody overtakes it (FIFO),
         for i, s in enumerate(self.slots):                          # but every later slot still gets its own code (-1 running, -2 idle)
             if s is not None:
                 row_class[i] = -1                                   # continue
@@ -280,7 +323,8 @@ class ContinuousLLMEngine:
                     raise ValueError("request %s asks for %d tokens, the session holds %d" % (r.request_id, r.params.max_tokens, self.session_tokens))
                 if self.cfg and not self.text and not self.pending_null:
                     continue                                        # its null-class partner has not arrived yet
-                if not self._reserve(i, r):
+                if not self._reserve(i, r, 1 if grow else None):
+                    self.deferred += 1
                     if not any(self.slots):
                         raise ValueError("request %s does not fit the KV pool even when it is empty" % r.request_id)
                     blocked = True                                  # FIFO: wait for blocks instead of overtaking
