@@ -836,6 +836,15 @@ def test_fragment_major_layouts_are_bit_identical():
             if ref is None:
                 ref = out
             assert torch.equal(out, ref), (rows, wfm, afm)
+    m.pdecode = False            # small row counts on the launch chain: A-fragment-major tiles with 15 / 11 padding rows
+    for rows in (1, 5):
+        ref = None
+        for wfm, afm in ((False, False), (True, True)):
+            m.weights_fm, m.act_fm = wfm, afm
+            out = V.generate_t2v(m, cond[:rows], 12, mask[:rows])
+            if ref is None:
+                ref = out
+            assert torch.isfinite(out).all() and torch.equal(out, ref), (rows, wfm, afm)
     t = V.Transformer(V.ModelArgs(dim=1024, n_layer=2, n_head=16, block_size=576, cls_token_num=1, model_type="c2i")).to("cuda", torch.bfloat16)
     t.init_random_weights(seed=1)
     cls = torch.randint(0, 1000, (12,), generator=torch.Generator().manual_seed(0)).to("cuda")

@@ -991,11 +991,11 @@ struct Runner {
 
   // The activation matrices of a fused decode step (x, attention output, SwiGLU output) A-fragment-major (gpt_kernels.h afm_index)?
   // Where every consumer is a fused GEMM of this chain: the launch chain (not the persistent step, which hands activations over in its own
-  // format), uniform positions (sessions gather their rows row-major), norms as GEMM prologues (the stand-alone RMSNorm reads rows).
+  // format) with the norms as GEMM prologues (the stand-alone RMSNorm reads rows); uniform positions and sessions alike.
   bool afm_ok() {
     static const bool off = getenv("VLG_ACT_FM") != nullptr && atoi(getenv("VLG_ACT_FM")) == 0;   // A/B knob
     const int D = h->D, F = h->F;
-    if (off || !h->act_fm || row_pos != nullptr || !fused_decode_ok() || pd_use()) return false;
+    if (off || !h->act_fm || !fused_decode_ok() || pd_use()) return false;
     if ((D * (int)sizeof(T)) % 64 != 0 || (F * (int)sizeof(T)) % 64 != 0) return false;
     bool ok = gemm_fused_ok<T>(Bp, 3 * D, D, true, EPI_QKV) && gemm_fused_ok<T>(Bp, F, D, true, EPI_SWIGLU);
     if (h->cfg.head == VLG_HEAD_LOGITS) ok = ok && gemm_fused_ok<T>(Bp, h->V, D, true, EPI_STORE);
@@ -1045,9 +1045,9 @@ struct Runner {
   int session_step(const vlg_sampling_params& sp, const int32_t* row_cls, int32_t* out_ids) {
     const int D = h->D;
     const T* cls_table = h->cfg.model_type == VLG_C2I ? W<T>("cls_embedding.embedding_table.weight") : nullptr;
+    afm = afm_ok();
     VLG_TRY(gather_session_rows<T>(cls_table, h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V, row_cls, ln->cur_tok.as<int32_t>(),
-                                   reinterpret_cast<const T*>(pending), ln->x.as<T>(), Bp, D, st));
-    afm = false;
+                                   reinterpret_cast<const T*>(pending), ln->x.as<T>(), Bp, D, st, afm ? D * (int)sizeof(T) / 64 : 0));
     if (fused_decode_ok()) {
       VLG_TRY(layers_fused());
       return head_fused(sp, nullptr, out_ids, nullptr, nullptr);

@@ -300,7 +300,7 @@ int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
 template <typename T>
 int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok,
-                        const T* pending, T* out, int rows, int D, hipStream_t st);   // row_cls: >= 0 class id, -3 pending row, else token
+                        const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks = 0);   // row_cls: >= 0 class id, -3 pending row, else token; out_nks > 0: out is A-fragment-major
 
 // sampler (sampler.hip) -----------------------------------------------------------------------
 // logits fp32 [Bp, V]; writes out_ids[b*N + step] (if out_ids), cur_tok[b] (and [b+B] when cfg_on),

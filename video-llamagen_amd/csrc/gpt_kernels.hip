@@ -1300,7 +1300,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gather_session_rows_kernel(const T* __restrict__ cls_table, int n_cls, const T* __restrict__ tok_table,
                                                                   int n_tok, const int32_t* __restrict__ row_cls,
                                                                   const int32_t* __restrict__ cur_tok, const T* __restrict__ pending,
-                                                                  T* __restrict__ out, int D) {
+                                                                  T* __restrict__ out, int D, int out_nks) {
   const int m = blockIdx.x;
   const int c = row_cls[m];
   const T* src;
@@ -1313,17 +1313,18 @@ __global__ __launch_bounds__(256) void gather_session_rows_kernel(const T* __res
     tk = tk < 0 ? 0 : (tk >= n_tok ? n_tok - 1 : tk);
     src = tok_table + (size_t)tk * D;
   }
-  for (int i = threadIdx.x; i < D; i += 256) out[(size_t)m * D + i] = src[i];
+  for (int i = threadIdx.x; i < D; i += 256) out[out_nks ? afm_index<T>(m, i, out_nks) : (size_t)m * D + i] = src[i];
 }
 template <typename T>
 int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok,
-                        const T* pending, T* out, int rows, int D, hipStream_t st) {
-  gather_session_rows_kernel<T><<<rows, 256, 0, st>>>(cls_table, n_cls, tok_table, n_tok, row_cls, cur_tok, pending, out, D);
+                        const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks) {
+  gather_session_rows_kernel<T><<<rows, 256, 0, st>>>(cls_table, n_cls, tok_table, n_tok, row_cls, cur_tok, pending, out, D, out_nks);
   return VLG_OK;
 }
 template int gather_session_rows<float>(const float*, int, const float*, int, const int32_t*, const int32_t*, const float*, float*, int, int,
-                                        hipStream_t);
-template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, const bf16*, bf16*, int, int, hipStream_t);
+                                        hipStream_t, int);
+template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, const bf16*, bf16*, int, int, hipStream_t,
+                                       int);
 
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;
