@@ -159,7 +159,8 @@ int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value);
  * Option "debug_spin_max" (default 0 = the built-in bound of ~1 s): spin bound of every in-launch wait; 1 makes the first wait that is
  * not satisfied at once give up - how the tests inject a time-out without oversubscribing the chip.
  * EXCLUSIVITY: a persistent launch wants one workgroup on every compute unit of the device.  One process per GPU with one generate() in
- * flight (the deployment this library is built for) always satisfies that.  Two PROCESSES that share one GPU and both run persistent
+ * flight (the deployment this library is built for) always satisfies that; inside one process the decode loops of different handles
+ * and host threads are chained on the device (each waits for the previous one's last step), so they cannot starve each other either.  Two PROCESSES that share one GPU and both run persistent
  * launches can split the compute units between them; both then time out (observed with two benchmark ranks on one card: VLG_ERR_STATE on
  * the first decode step, never wrong results).  When a GPU is shared, set options "pdecode" = 0 and "dl_persist" = 0: the per-layer launch
  * chains need no residency.                                                                                                        */

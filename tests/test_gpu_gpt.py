@@ -871,3 +871,40 @@ def test_fragment_major_copies_follow_a_weight_reload():
     b = V.Transformer(V.ModelArgs(**args)).to("cuda", torch.bfloat16)
     b.init_random_weights(seed=2)
     assert torch.equal(ids2, V.generate(b, cls, 24, cfg_scale=2.0, sample_logits=False)) and not torch.equal(ids1, ids2)
+
+
+def test_persistent_steps_of_two_handles_and_threads_do_not_starve_each_other():
+    """A persistent launch wants every compute unit: two of them in flight on one device can each hold part of the chip and time out
+    (VLG_ERR_STATE - observed with two benchmark RANKS, i.e. processes, on one card).  Inside one process the library chains the decode
+    loops of its handles on the device (PersistGate, gpt.hip).  This is the concurrency smoke test of that path: two host threads
+    generating at once from two handles on two streams must both succeed and reproduce their single-threaded ids.  (With launches this
+    short the starvation itself does not reproduce in-process - VLG_PERSIST_GATE=0 passes too - so the test guards the gate's
+    correctness, not its necessity.)"""
+    import threading
+    import video_llamagen_amd as V
+    cfg = cases.TINY_C2I
+    models = [product_gpt(cfg, torch.float32)[0] for _ in range(2)]
+    conds = [torch.from_numpy(cases.class_ids(3, cfg["num_classes"])), torch.tensor([1, 7])]
+    want = [V.generate(m, c, cfg["block_size"], cfg_scale=2.5, sample_logits=False).cpu() for m, c in zip(models, conds)]
+    assert all(m.counter("pd_steps") > 0 for m in models)
+    errs, got = [], [[], []]
+    go = threading.Barrier(2)
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                go.wait()
+                for _ in range(20):
+                    got[i].append(V.generate(models[i], conds[i], cfg["block_size"], cfg_scale=2.5, sample_logits=False).cpu())
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert len(got[i]) == 20 and all(torch.equal(o, want[i]) for o in got[i])

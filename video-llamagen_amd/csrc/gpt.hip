@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <mutex>
 
 #include "conv_kernels.h"
 #include "gpt_kernels.h"
@@ -1143,6 +1144,19 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   return VLG_OK;
 }
 
+// Persistent kernels (decode step, DiffLoss sampler) want every compute unit; two of them in flight on one device can starve each other
+// until their bounded waits run out (VLG_ERR_STATE).  Inside ONE process the decode loops of different handles / host threads are
+// therefore chained on the device: a loop waits for the event the previous loop recorded behind its last step.  (Other processes on
+// the same GPU are out of reach: include/vlg.h, "EXCLUSIVITY".)
+struct PersistGate {
+  std::mutex mu;
+  hipEvent_t ev[64] = {};
+};
+static PersistGate& persist_gate() {
+  static PersistGate g;
+  return g;
+}
+
 template <typename T>
 int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, int N, const vlg_sampling_params& sp,
                   const float* d_noise, int32_t* out_ids, float* out_lat, float* trace, hipStream_t caller) {
@@ -1186,6 +1200,20 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   hipStream_t s0 = r.st;
   const int steps = N - 1;
+  std::unique_lock<std::mutex> gate_lock;
+  hipEvent_t gate_ev = nullptr;
+  static const bool gate_off = getenv("VLG_PERSIST_GATE") != nullptr && atoi(getenv("VLG_PERSIST_GATE")) == 0;   // tests: show what the gate prevents
+  if (!gate_off && steps > 0 && (h->pdecode || (h->cfg.head == VLG_HEAD_HIDDEN && h->dl_persist_on))) {
+    int dev = 0;
+    VLG_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64) {
+      PersistGate& g = persist_gate();
+      gate_lock = std::unique_lock<std::mutex>(g.mu);
+      if (!g.ev[dev]) VLG_HIP(hipEventCreateWithFlags(&g.ev[dev], hipEventDisableTiming));
+      gate_ev = g.ev[dev];
+      VLG_HIP(hipStreamWaitEvent(s0, gate_ev, 0));   // the previous decode loop of this process on this device (any handle, any thread)
+    }
+  }
   if (steps > 0) {
     if (h->time_attn) {
       // eager loop; HIP events (on the launch stream) around layer 0's attention kernel
@@ -1270,6 +1298,10 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     } else {
       for (int i = 0; i < steps; ++i) VLG_TRY(r.decode_step(sp, d_noise, out_ids, out_lat, trace));
     }
+  }
+  if (gate_ev) {
+    VLG_HIP(hipEventRecord(gate_ev, s0));
+    gate_lock.unlock();
   }
   // ---- join back into the caller's stream ---------------------------------------------------------------------------
   VLG_HIP(hipEventRecord(ln->ev, r.st));
