@@ -127,11 +127,17 @@ __device__ __forceinline__ void mfma_one(const u32x4_t& a, const u32x4_t& b, f32
 // NC: output columns per workgroup.  8 (EPI_RESID at M <= 16 only): lanes 8..15 of a 16-lane group mirror lanes 0..7 (same weight row,
 // same column, results dropped) - half of the MFMA tile is wasted, but twice the workgroups stream the two N = D matrices, whose 80
 // 16-column tiles leave 2/3 of the CUs idle while each busy one is bound by its own miss-handling rate.
-template <typename T, int MT, int NW, bool PRO, int EPI, int NC = 16>
+// NT: 16-column n-tiles per workgroup.  2 (with MT = 1 and the two 16-row halves of the batch as grid rows) for the kernels with the RMSNorm
+// prologue at 17..32 rows: every workgroup normalises ALL activation elements of its rows (it needs the whole K range), and that VALU work
+// is 1.5 us of a QKV / w13 launch - a workgroup of 16 rows x 32 columns does half of it and reads half the
+// activation bytes for the same number of workgroups (the second reader of a weight tile hits its XCD's L2, as for wo / w2).
+template <typename T, int MT, int NW, bool PRO, int EPI, int NC = 16, int NT = 1>
 __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict__ x, const T* __restrict__ w, int M, int N, int K, FusedGemm fa) {
   static_assert(NC == 16 || (NC == 8 && EPI == EPI_RESID && !PRO), "8-column tiles: residual epilogue only");
+  static_assert(NT == 1 || (NT == 2 && NC == 16 && MT == 1), "two n-tiles: 16-row workgroups of 16-column tiles");
   constexpr int KBLK = KB<T>::KBLK;
-  constexpr int NH = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int NHH = (EPI == EPI_SWIGLU) ? 2 : 1;   // weight tiles per output tile (w1 and w3 rows of the same columns)
+  constexpr int NH = NHH * NT;                        // weight tiles per workgroup: index nt * NHH + half
   constexpr int NB = (MT * NH >= 4) ? 2 : 4;
   constexpr int EPV = 16 / sizeof(T);   // elements per 16-byte vector
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
     bx = (id & 7) + 8 * (id >> 4);
     by = (id >> 3) & 1;
   }
-  const int n0 = bx * NC, m0 = by * (MT * 16);
+  const int n0 = bx * (NC * NT), m0 = by * (MT * 16);
   const int nkb = K / KBLK;
   VLG_KT(0);
 
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   const int w_sstep = fm ? 64 : 4, w_kstep = fm ? 256 : (int)(KBLK * sizeof(T) / 16);
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf) {
-    const int ncol = n0 + (NH == 2 ? hf * N : 0);
+    const int ncol = n0 + (hf / NHH) * 16 + (hf % NHH) * N;
     if (fm)
       wbase[hf] = reinterpret_cast<const u32x4_t*>(fa.wfm) + (size_t)(ncol >> 4) * ((size_t)nkb * 256) + ((ncol & 15) + (r & (NC - 1))) + 16 * q;
     else
@@ -192,10 +198,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   // (HBM), then the epilogue operands that do not depend on the GEMM (residual rows; RoPE pair of the current position).  The
   // norm prologue then runs on the activations while the weights are still in flight, and the epilogue never waits on memory.
   const int et = threadIdx.x, ee = et >> 6, el = et & 63;
-  const int ecol = n0 + (el & (NC - 1));
-  float eres[MT], ecx[MT], ecy[MT];   // ecx doubles as the gate value for EPI_GATED
+  const int ecol0 = n0 + (el & (NC - 1));   // output column of n-tile 0; n-tile nt: + 16 nt
+  float eres[NT][MT], ecx[NT][MT], ecy[NT][MT];   // ecx doubles as the gate value for EPI_GATED
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) eres[mt] = 0.f, ecx[mt] = 1.f, ecy[mt] = 0.f;
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) eres[nt][mt] = 0.f, ecx[nt][mt] = 1.f, ecy[nt][mt] = 0.f;
   int epos = 0;
   const int32_t* erow_pos = nullptr;   // iteration-level batching: per-row positions (a kernel argument, no dependent load)
   if constexpr (EPI == EPI_QKV) {
@@ -205,25 +213,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   auto epilogue_operands = [&]() {
     if constexpr (EPI == EPI_RESID || EPI == EPI_GATED) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
-        row = row < M ? row : M - 1;
-        eres[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + oidx(row, ecol));
-        if constexpr (EPI == EPI_GATED) ecx[mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.gate) + (size_t)row * fa.gate_stride + ecol);
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
+          row = row < M ? row : M - 1;
+          eres[nt][mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.h) + oidx(row, ecol0 + nt * 16));
+          if constexpr (EPI == EPI_GATED) ecx[nt][mt] = DT<T>::ld(reinterpret_cast<const T*>(fa.gate) + (size_t)row * fa.gate_stride + ecol0 + nt * 16);
+        }
     }
     if constexpr (EPI == EPI_QKV) {
       const int D = fa.H * fa.hd;
-      const int d = (ecol % D) % fa.hd;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
-        row = row < M ? row : M - 1;
-        // uniform position: sessions (per-row positions) reload their pair in the epilogue - a per-row load here would put a
-        // branch and a dependent load in front of the weight stream
-        const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
-        ecx[mt] = cp[0];
-        ecy[mt] = cp[1];
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = ((ecol0 + nt * 16) % D) % fa.hd;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int row = m0 + mt * 16 + (el >> 4) * 4 + ee;
+          row = row < M ? row : M - 1;
+          // uniform position: sessions (per-row positions) reload their pair in the epilogue - a per-row load here would put a
+          // branch and a dependent load in front of the weight stream
+          const float* cp = fa.freqs + ((size_t)(epos + row % fa.Tq) * (fa.hd / 2) + d / 2) * 2;
+          ecx[nt][mt] = cp[0];
+          ecy[nt][mt] = cp[1];
+        }
       }
     }
   };
@@ -346,26 +359,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
   VLG_KT(2);
   const int t = threadIdx.x;
   const int e = t >> 6, l2 = t & 63;
-  const int col = n0 + (l2 & (NC - 1));
   if (t >= 256) return;
 #pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    const int col = n0 + nt * 16 + (l2 & (NC - 1));
     const int row = m0 + mt * 16 + (l2 >> 4) * 4 + e;
     float s0 = 0.f, s1 = 0.f, sp = 0.f;
 #pragma unroll
     for (int wv = 0; wv < NW; ++wv) {
-      s0 += red[wv][0][mt][t];
-      if constexpr (NH == 2) s1 += red[wv][1][mt][t];
-      if constexpr (EPI == EPI_QKV) sp += red[wv][0][mt][t ^ 1];
+      s0 += red[wv][nt * NHH][mt][t];
+      if constexpr (NHH == 2) s1 += red[wv][nt * NHH + 1][mt][t];
+      if constexpr (EPI == EPI_QKV) sp += red[wv][nt * NHH][mt][t ^ 1];
     }
     if (row >= M) continue;
     if (NC == 8 && (l2 & 8)) continue;   // mirror lanes
     if constexpr (EPI == EPI_RESID) {
-      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[mt] + DT<T>::rt(s0));
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[nt][mt] + DT<T>::rt(s0));
     } else if constexpr (EPI == EPI_GATED) {
       float v = s0;
       if (fa.bias) v += DT<T>::ld(reinterpret_cast<const T*>(fa.bias) + col);
-      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[mt] + DT<T>::rt(ecx[mt] * DT<T>::rt(v)));
+      DT<T>::st(reinterpret_cast<T*>(fa.h) + oidx(row, col), eres[nt][mt] + DT<T>::rt(ecx[nt][mt] * DT<T>::rt(v)));
     } else if constexpr (EPI == EPI_SWIGLU) {
       const float av = DT<T>::rt(s0), bv = DT<T>::rt(s1);
       DT<T>::st(reinterpret_cast<T*>(fa.out) + oidx(row, col), DT<T>::rt(silu_g(av)) * bv);
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fused_kernel(const T* __restrict
       const float xs = DT<T>::rt(s0), xp = DT<T>::rt(sp);
       float o = xs;
       if (sec < 2) {
-        float cx = ecx[mt], cy = ecy[mt];
+        float cx = ecx[nt][mt], cy = ecy[nt][mt];
         if (erow_pos) {
           const float* cp = fa.freqs + ((size_t)p * (fa.hd / 2) + d / 2) * 2;
           cx = cp[0];
@@ -625,6 +640,19 @@ int gemm_fused(const T* x, const T* w, int M, int N, int K, bool pro, int epi, c
       gemm_fused_kernel<T, 1, 8, false, EPI_RESID, 8><<<grid, 512, 0, st>>>(x, w, M, N, K, fa);
     else
       gemm_fused_kernel<T, 1, 4, false, EPI_RESID, 8><<<grid, 256, 0, st>>>(x, w, M, N, K, fa);
+    return VLG_OK;
+  }
+  // RMSNorm-prologue kernels at 17..32 rows: 16 rows x two n-tiles per workgroup (NT = 2), the two row halves as grid rows paired on an XCD:
+  // half the normalisation work and half the activation bytes per workgroup, the same number of workgroups
+  static const int nt2_knob = lds_knob("VLG_GEMM_NT2", 1);
+  if (nt2_knob && pro && mt == 2 && (epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_STORE) && N % 32 == 0 && (N / 32) % 8 == 0) {
+    const dim3 g2(N / 32, cdiv(M, 16));
+    if (epi == EPI_SWIGLU)
+      gemm_fused_kernel<T, 1, 8, true, EPI_SWIGLU, 16, 2><<<g2, 512, 0, st>>>(x, w, M, N, K, fa);
+    else if (epi == EPI_QKV)
+      gemm_fused_kernel<T, 1, 4, true, EPI_QKV, 16, 2><<<g2, 256, 0, st>>>(x, w, M, N, K, fa);
+    else
+      gemm_fused_kernel<T, 1, 4, true, EPI_STORE, 16, 2><<<g2, 256, 0, st>>>(x, w, M, N, K, fa);
     return VLG_OK;
   }
 #define VLG_GF(MT_, NW_)                                                            \
