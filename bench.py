@@ -65,7 +65,7 @@ def build_gpt(V, a, device, head=None):
 
 
 # one-GPU timings of the per-GPU shards of the 32-video job (bench.py --batch b --no-vae, + b/4 VAE decode calls of 0.11 s), DESIGN.md section 6
-PROJECTED_STRONG = {"basis_s_per_step": {"32": 19.2, "16": 12.2, "8": 8.9, "4": 6.6}, "speedup": {"2": 1.57, "4": 2.17, "8": 2.9}}
+PROJECTED_STRONG = {"basis_s_per_step": {"32": 18.9, "16": 12.2, "8": 8.9, "4": 6.6}, "speedup": {"2": 1.55, "4": 2.12, "8": 2.86}}
 
 
 def synth_cond(B, device, seed):
