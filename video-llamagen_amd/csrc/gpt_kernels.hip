@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const T* __restrict__ x,
 // register-staged, 16-byte-chunk XOR swizzle); each wave streams only its own weight rows (non-temporal): 1 : 1.
 // Output: fp32 slabs like gemm_mfma_kernel (gridDim.z K-slices), consumed by the reduce_* kernels.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool NT>   // NT: non-temporal weight loads (one row block: every weight byte is read once)
+template <typename T, bool NT, bool FM = false>   // NT: non-temporal weight loads (one row block: every weight byte is read once); FM: fragment-major weights
 __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x, const T* __restrict__ w, float* __restrict__ slabs, int M,
                                                         int N, int K) {
   constexpr int KBLK = GemmT<T>::KBLK;   // 256 bytes per row per K block for both dtypes
@@ -245,8 +245,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
     asrc[i] = reinterpret_cast<const u32x4_t*>(x + (size_t)gr * K) + ch;
     aslot[i] = row * 16 + (ch ^ (row & 15));
   }
-  const u32x4_t* wsrc = reinterpret_cast<const u32x4_t*>(w + (size_t)(n0 + r) * K) + q;
   constexpr int CPB = KBLK * (int)sizeof(T) / 16;   // 16-byte chunks per row per K block = 16
+  // weight chunk s2 of K block kb: row-major = this lane's row, chunk kb * 16 + 4 s2 + q; fragment-major (relayout_fragment_major) = block
+  // (n-tile, K step 4 kb + s2), slot `lane`: whole-line requests
+  constexpr int WSTEP = FM ? 64 : 4, WBLK = FM ? 256 : CPB;
+  const u32x4_t* wsrc = FM ? reinterpret_cast<const u32x4_t*>(w) + (size_t)(n0 / 16) * ((size_t)nkb * 256) + lane
+                           : reinterpret_cast<const u32x4_t*>(w + (size_t)(n0 + r) * K) + q;
 
   f32x4_t acc[4];
 #pragma unroll
@@ -260,9 +264,9 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       if constexpr (NT)
-        b[s2] = __builtin_nontemporal_load(wsrc + (size_t)kb * CPB + s2 * 4);
+        b[s2] = __builtin_nontemporal_load(wsrc + (size_t)kb * WBLK + s2 * WSTEP);
       else
-        b[s2] = wsrc[(size_t)kb * CPB + s2 * 4];   // several row blocks (prefill) re-read the tile: let L2 keep it
+        b[s2] = wsrc[(size_t)kb * WBLK + s2 * WSTEP];   // several row blocks (prefill) re-read the tile: let L2 keep it
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) As[0][aslot[i]] = ra[i];
@@ -278,9 +282,9 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       if constexpr (NT)
-        bn[s2] = __builtin_nontemporal_load(wsrc + (size_t)kl * CPB + s2 * 4);
+        bn[s2] = __builtin_nontemporal_load(wsrc + (size_t)kl * WBLK + s2 * WSTEP);
       else
-        bn[s2] = wsrc[(size_t)kl * CPB + s2 * 4];
+        bn[s2] = wsrc[(size_t)kl * WBLK + s2 * WSTEP];
     }
     u32x4_t af[4][4];
 #pragma unroll
@@ -519,7 +523,13 @@ int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* spli
     return VLG_OK;
   }
   if (wide) {
-    if (mchunks == 1)
+    static const bool fm_off_w = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;
+    if (wfm != nullptr && !fm_off_w) {
+      if (mchunks == 1)
+        gemm_wide_kernel<T, true, true><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, wfm, ws, M, N, K);
+      else
+        gemm_wide_kernel<T, false, true><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, wfm, ws, M, N, K);
+    } else if (mchunks == 1)
       gemm_wide_kernel<T, true><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
     else
       gemm_wide_kernel<T, false><<<dim3(N / 64, mchunks, splits), 256, 0, st>>>(x, w, ws, M, N, K);
