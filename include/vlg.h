@@ -93,7 +93,10 @@ typedef struct {
  *               [N, num_sampling_steps + 1, B, C] N(0,1) draws (x_T, then one per reverse step); NULL -> Philox(seed)
  *   d_out_ids   int32 [B, N]            (logits head)
  *   d_out_lat   fp32  [B, N, vae_embed_dim]  (adapter2 / hidden head)
- *   d_trace     optional fp32 [N, B, vocab|C]: the CFG-combined head output fed to the sampler */
+ *   d_trace     optional fp32 [N, B, vocab|C]: the CFG-combined head output fed to the sampler
+ * Stream contract: the call returns with the work enqueued behind `stream` and its results ordered on `stream`.  Results are staged in a
+ * handle-owned buffer and copied out on `stream` at the end: issue the calls of ONE handle from one stream (or synchronise between
+ * streams), as with any torch module - a second call from another stream could overwrite the staging buffer under the first copy. */
 int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, int32_t B, int32_t N,
                      const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids,
                      float* d_out_lat, float* d_trace, void* stream);
@@ -230,7 +233,9 @@ int vlg_vq_encode(vlg_vq_t* h, const float* d_x, int32_t B, int32_t Hh, int32_t 
  * d_z fp32 [n, dim] rows, d_codebook fp32 [n_codes, dim] -> int32 [n] (no normalisation)              */
 int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim,
                         int32_t* d_idx, void* stream);
-/* Codebook.forward in eval mode, tokenizer_video/vqvae.py:161-209 (== CausalVideoVAE quant.py:42-96):
+/* (vlg_codebook_argmin / vlg_codebook_forward keep their code norms, usage histogram and partial sums in one process-wide scratch:
+ *  call them from one stream at a time.)
+ * Codebook.forward in eval mode, tokenizer_video/vqvae.py:161-209 (== CausalVideoVAE quant.py:42-96):
  * d_z fp32 [B, dim, n_pos] (the reference's [b, c, t, h, w] with n_pos = t*h*w), d_codebook fp32 [n_codes, dim] ->
  *   d_encodings        int32 [B, n_pos]        nearest code per position (first minimum)
  *   d_embeddings_st    fp32  [B, dim, n_pos]   (E[idx] - z) + z, the straight-through output        (optional, with the next)
