@@ -131,6 +131,19 @@ template <typename T>
 const T* W(vlg_t5* h, const std::string& n) {
   return h->w.at(n).buf.as<T>();
 }
+// fragment-major copy of a Linear weight (gpt_kernels.h: relayout_fragment_major), built on first use after a load; null where the shape
+// does not tile
+template <typename T>
+const T* Wfm(vlg_t5* h, const std::string& n, hipStream_t st) {
+  Tensor& t = h->w.at(n);
+  if (t.shape.size() != 2 || !fragment_major_ok((int)t.shape[0], (int)t.shape[1], (int)sizeof(T))) return nullptr;
+  if (t.fm_stale) {
+    if (t.fm.reserve((size_t)t.shape[0] * t.shape[1] * sizeof(T)) != VLG_OK) return nullptr;
+    if (relayout_fragment_major<T>(t.buf.as<T>(), t.fm.as<T>(), (int)t.shape[0], (int)t.shape[1], st) != VLG_OK) return nullptr;
+    t.fm_stale = false;
+  }
+  return t.fm.as<T>();
+}
 
 template <typename T>
 int encode_impl(vlg_t5* h, const int64_t* d_ids, const float* d_mask, int B, int Tn, float* d_out, hipStream_t caller) {
@@ -162,15 +175,15 @@ int encode_impl(vlg_t5* h, const int64_t* d_ids, const float* d_mask, int B, int
   for (int l = 0; l < c.num_layers; ++l) {
     const std::string p = "encoder.block." + std::to_string(l) + ".layer.";
     int sp = 1;
-    VLG_TRY(gemm_slabs<T>(xn, W<T>(h, p + "0.SelfAttention.qkv"), ws, M, 3 * inner, D, &sp, st));
+    VLG_TRY(gemm_slabs<T>(xn, W<T>(h, p + "0.SelfAttention.qkv"), ws, M, 3 * inner, D, &sp, st, Wfm<T>(h, p + "0.SelfAttention.qkv", st)));
     VLG_TRY(reduce_store<T>(ws, sp, h->qkv.as<T>(), nullptr, M, 3 * inner, ACT_NONE, st));
     t5_attn_kernel<T><<<dim3(Tn, H, B), 256, (size_t)(dk + Tn + 8) * sizeof(float), st>>>(h->qkv.as<T>(), h->bias.as<float>(), d_mask, h->att.as<T>(), Tn,
                                                                                          H, dk, neg);
-    VLG_TRY(gemm_slabs<T>(h->att.as<T>(), W<T>(h, p + "0.SelfAttention.o.weight"), ws, M, D, inner, &sp, st));
+    VLG_TRY(gemm_slabs<T>(h->att.as<T>(), W<T>(h, p + "0.SelfAttention.o.weight"), ws, M, D, inner, &sp, st, Wfm<T>(h, p + "0.SelfAttention.o.weight", st)));
     VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(h, p + "1.layer_norm.weight"), xn, M, D, eps, st));
-    VLG_TRY(gemm_slabs<T>(xn, W<T>(h, p + "1.DenseReluDense.wi"), ws, M, 2 * F, D, &sp, st));
+    VLG_TRY(gemm_slabs<T>(xn, W<T>(h, p + "1.DenseReluDense.wi"), ws, M, 2 * F, D, &sp, st, Wfm<T>(h, p + "1.DenseReluDense.wi", st)));
     reduce_gelu_mul_kernel<T><<<(unsigned)cdiv64((long long)M * F, 256), 256, 0, st>>>(ws, sp, h->g.as<T>(), M, F);
-    VLG_TRY(gemm_slabs<T>(h->g.as<T>(), W<T>(h, p + "1.DenseReluDense.wo.weight"), ws, M, D, F, &sp, st));
+    VLG_TRY(gemm_slabs<T>(h->g.as<T>(), W<T>(h, p + "1.DenseReluDense.wo.weight"), ws, M, D, F, &sp, st, Wfm<T>(h, p + "1.DenseReluDense.wo.weight", st)));
     const std::string nxt = l + 1 < c.num_layers ? "encoder.block." + std::to_string(l + 1) + ".layer.0.layer_norm.weight"
                                                  : std::string("encoder.final_layer_norm.weight");
     VLG_TRY(reduce_residual_rmsnorm<T>(ws, sp, x, W<T>(h, nxt), xn, M, D, eps, st));
@@ -276,6 +289,7 @@ extern "C" int vlg_t5_load_tensor(vlg_t5_t* h, const char* name, const void* dat
   int& got = h->parts[target];
   got |= 1 << part;
   t.loaded = got == (1 << nparts) - 1;   // a merged tensor is complete once q, k, v (wi_0, wi_1) all came in
+  t.fm_stale = true;                     // the fragment-major copy is rebuilt at the next encode
   if (consumed) *consumed = 1;
   return VLG_OK;
 }
