@@ -457,17 +457,20 @@ def main():
                 extras["C4_diffloss_head"] = {"workload": f"{a.gpt_model} t2v, hidden head + DiffLoss sampler (100 DDPM steps per token, gpt_video_diff.py), "
                                                           f"{B} videos, first {nh} of 5120 latent tokens (positions 120..{119 + nh}), bf16, sampling only",
                                               "sampling_s": dth, "tokens_per_s": B * nh / dth, "ms_per_token_step": 1e3 * dth / nh}
-                if elapsed() + 6 <= a.budget_s:
+                if elapsed() + 8 <= a.budget_s:
                     # the same head at LATE context: positions 4984..5239 (the last 256 of the 5120 latent tokens) over a zero-filled cache
                     # prefix (handle option debug_pos_offset) - what a token step costs where attention reads the whole context
                     off = a.latent ** 2 * ((a.num_frames - 1) // 4 + 1) - nh
                     gh.debug_pos_offset = off
-                    V.generate_t2v(gh, cond, 2, mask)            # allocation of the full-length cache outside the timed call
-                    torch.cuda.synchronize()
-                    t = time.perf_counter()
-                    V.generate_t2v(gh, cond, nh, mask)
-                    torch.cuda.synchronize()
-                    dtl = time.perf_counter() - t
+                    V.generate_t2v(gh, cond, 2, mask)            # allocation of the full-length cache outside the timed calls
+                    dtl = None
+                    for _ in range(2):                           # best of two: the first call after a 31 GB allocation has measured 40 % high once
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        V.generate_t2v(gh, cond, nh, mask)
+                        torch.cuda.synchronize()
+                        d = time.perf_counter() - t
+                        dtl = d if dtl is None else min(dtl, d)
                     extras["C4_diffloss_head_late"] = {"workload": f"as C4_diffloss_head, last {nh} of the 5120 latent tokens (positions {120 + off}..{119 + off + nh}; "
                                                                    "earlier cache rows zero-filled)",
                                                        "sampling_s": dtl, "tokens_per_s": B * nh / dtl, "ms_per_token_step": 1e3 * dtl / nh}
