@@ -252,6 +252,24 @@ def test_kv_block_growth_and_preemption_vs_reference_golden(golden):
     with pytest.raises(ValueError):
         V.ContinuousLLMEngine(m, kv_block_size=8, kv_policy="swap")
 
+    # text-conditioned requests (condition prefilled per slot): 120 condition positions + 16 tokens = 9 blocks of 16 per row.  Two slots,
+    # 8 + 8 blocks at admission (120 + 1 positions), the 9th block of the older request is the last free one: the younger is preempted
+    # when it needs its own, re-prefilled and run again later
+    cfg = cases.TINY_T2I
+    m, _ = product_gpt(cfg, torch.float32)
+    c, mk = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[120, 3, 57])
+    N = cfg["block_size"]
+    e = V.ContinuousLLMEngine(m, cfg_scale=1.0, max_num_seqs=2, kv_block_size=16, num_kv_blocks=1 + 17, kv_policy="grow")
+    for i in range(3):
+        e.add_request(str(i), None, V.SamplingParams(temperature=0.0, max_tokens=N), prompt_embeds=torch.from_numpy(c[i]), emb_mask=torch.from_numpy(mk[i]))
+    outs, steps = {}, 0
+    while e.has_unfinished_requests():
+        for o in e.step():
+            outs[int(o.request_id)] = o.outputs[0].token_ids
+        steps += 1
+        assert steps < 400
+    assert e.preempted >= 1 and (np.array([outs[i] for i in range(3)]) == g["t2i_fp32_greedy_ids"]).all()
+
 
 def test_block_granular_kv_sessions_vs_reference_golden(golden):
     """The iteration-level engine on a block-granular KV cache (vlg_gpt_session_reserve / release, paged attention + paged KV append):
