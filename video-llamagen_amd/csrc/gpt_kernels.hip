@@ -426,8 +426,6 @@ __global__ __launch_bounds__(256) void gemm_tall_kernel(const T* __restrict__ x,
   float* cw = Cs[wave];
 #pragma unroll
   for (int p0 = 0; p0 < NTW; p0 += 2) {
-    constexpr int dummy = 0;
-    (void)dummy;
     const int ncols = (NTW - p0 >= 2) ? 32 : 16;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
