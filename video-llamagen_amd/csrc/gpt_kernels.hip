@@ -1035,6 +1035,103 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefill attention (Tq > 1 query rows per batch row, generate.py:77-86,156-165): one workgroup per (head, batch row).  The condition's
+// K and V rows (<= 120 x head_dim) are staged in LDS ONCE and every query row of the (b, h) pair is served from there - the split-KV decode
+// kernel walks the cache once per query row (76,800 workgroups for 32 x 120 rows x 20 heads: 106 us per layer; this form: 640 workgroups).
+// gridDim.z workgroups share a (b, h) pair when there are few pairs (each stages K / V again: 30 KB).  Wave w takes rows w, w + 4, ...: lanes = keys for the scores (q broadcast from LDS, K row per lane), lanes = head dims for P.V (one
+// probability broadcast per key).  fp32 scores / softmax / accumulation as the decode kernel; the same mask rule (a padded condition key
+// is dropped unless it is the row's own position).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void prefill_attn_kernel(const T* __restrict__ qbuf, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                           T* __restrict__ out, const StepState* __restrict__ state, int Tq, int H, int S, int nk,
+                                                           const float* __restrict__ mask, int Bmask, int Tc, float scale) {
+  constexpr int EPV = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
+  constexpr int ROWB = HD * (int)sizeof(T) + 16;           // LDS row pitch (+ 16 bytes: consecutive keys start on different banks)
+  constexpr int DPL = (HD + 63) / 64;                      // head dims per lane in the P.V phase
+  extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+  char* Ks = pf_smem;
+  char* Vs = Ks + (size_t)nk * ROWB;
+  float* qs = reinterpret_cast<float*>(Vs + (size_t)nk * ROWB);   // [4 waves][HD]
+  const int nkp = (nk + 63) / 64 * 64;
+  float* ps = qs + 4 * HD;                                          // [4 waves][nkp]
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pos = state->pos;
+  const T* kb = kc + ((size_t)b * H + h) * (size_t)S * HD;
+  const T* vb = vc + ((size_t)b * H + h) * (size_t)S * HD;
+  constexpr int CPR = HD * (int)sizeof(T) / 16;             // 16-byte chunks per row (HD * sizeof(T) % 16 == 0: launcher)
+  for (int i = threadIdx.x; i < nk * CPR; i += 256) {
+    const int row = i / CPR, c = i - row * CPR;
+    *reinterpret_cast<u32x4_t*>(Ks + (size_t)row * ROWB + c * 16) = reinterpret_cast<const u32x4_t*>(kb + (size_t)row * HD)[c];
+    *reinterpret_cast<u32x4_t*>(Vs + (size_t)row * ROWB + c * 16) = reinterpret_cast<const u32x4_t*>(vb + (size_t)row * HD)[c];
+  }
+  __syncthreads();
+  const float* mrow = (mask != nullptr) ? mask + (size_t)(b % Bmask) * Tc : nullptr;
+  float* qw = qs + wave * HD;
+  float* pw = ps + (size_t)wave * nkp;
+  for (int t = wave + 4 * blockIdx.z; t < Tq; t += 4 * gridDim.z) {   // rows interleaved over waves and the grid's z: causal lengths balance
+    const int m = b * Tq + t;
+    int p = pos + t;
+    p = p < nk ? p : nk - 1;                                 // host contract: pos + Tq <= nk
+    for (int d = lane; d < HD; d += 64) qw[d] = DT<T>::ld(qbuf + ((size_t)m * H + h) * HD + d);
+    // scores: key j = lane + 64 i
+    float sc[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = lane + 64 * i;
+      float dot = 0.f;
+      if (j <= p) {
+        const char* kr = Ks + (size_t)j * ROWB;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+          const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(kr + c * 16);
+          const T* ke = reinterpret_cast<const T*>(&kv);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) dot = fmaf(qw[c * EPV + e], DT<T>::ld(ke + e), dot);
+        }
+      }
+      bool ok = j <= p;
+      if (ok && mrow != nullptr && j < Tc && j != p) ok = mrow[j] != 0.f;
+      sc[i] = ok ? dot * scale : -INFINITY;
+      mx = fmaxf(mx, sc[i]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float mref = (mx == -INFINITY) ? 0.f : mx;
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = lane + 64 * i;
+      const float e = __expf(sc[i] - mref);
+      l += e;
+      if (j < nkp) pw[j] = e;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    // P.V: lane owns head dims lane, lane + 64
+    float acc[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc[k] = 0.f;
+    for (int j = 0; j <= p; ++j) {
+      const float pj = pw[j];
+      const T* vr = reinterpret_cast<const T*>(Vs + (size_t)j * ROWB);
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        const int d = lane + 64 * k;
+        if (d < HD) acc[k] = fmaf(pj, DT<T>::ld(vr + d), acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      const int d = lane + 64 * k;
+      if (d < HD) DT<T>::st(out + ((size_t)m * H + h) * HD + d, acc[k] / l);
+    }
+  }
+}
+
 size_t attn_ws_floats(int M, int H, int hd) { return (size_t)M * H * 16 * (hd + 2); }
 
 template <typename T, int HD, int VEC, int LPR>
@@ -1042,6 +1139,26 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
                        int S, int max_pos, const float* mask, int Bmask, int Tc, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                        const int32_t* row_pos, KvPages pages, int out_nks) {
   const int M = Bp * Tq;
+  {
+    // prefill (several query rows per batch row at uniform positions, contiguous cache): K / V staged once per (batch row, head)
+    static const bool pf_off = getenv("VLG_PREFILL_ATTN") != nullptr && atoi(getenv("VLG_PREFILL_ATTN")) == 0;   // A/B knob
+    const int nk = max_pos + 1;
+    const size_t lds = (size_t)2 * nk * (HD * sizeof(T) + 16) + (size_t)4 * HD * sizeof(float) + (size_t)4 * ((nk + 63) / 64 * 64) * sizeof(float);
+    if (!pf_off && Tq > 1 && nk <= 128 && nk >= Tq && row_pos == nullptr && pages.table == nullptr && out_nks == 0 && (HD * sizeof(T)) % 16 == 0 &&
+        lds <= 150 * 1024) {
+      static bool attr_set = false;   // per instantiation
+      if (!attr_set) {
+        VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefill_attn_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+      }
+      if (ev0) (void)hipEventRecord(ev0, st);
+      static const int z_knob = getenv("VLG_PREFILL_Z") ? atoi(getenv("VLG_PREFILL_Z")) : 0;   // A/B knob: workgroups per (b, h) pair
+      const int zs = z_knob > 0 ? std::min(z_knob, 30) : 8;   // measured 1 / 2 / 4 / 8 on 32 x 120 and 8 x 120 rows: 8 is fastest on both (staging K / V again costs less than idle CUs)
+      prefill_attn_kernel<T, HD><<<dim3(H, Bp, zs), 256, lds, st>>>(qbuf, kc, vc, out, state, Tq, H, S, nk, mask, Bmask, Tc, 1.0f / sqrtf((float)HD));
+      if (ev1) (void)hipEventRecord(ev1, st);
+      return VLG_OK;
+    }
+  }
   // grid sizing measured on MI355X with non-temporal KV loads (tools/bench_kernels.py attn, B'H = 640): 2560 workgroups
   // (nsplit 4) 72.8 us vs 1536-cap (nsplit 2) 74.8 us at p = 2679.  Not splitting at all (640 workgroups, 8 loads in flight)
   // saves the combine launch but the kernel itself runs 4.6 us longer inside the decode step (75.6 vs 71.0 us average):
