@@ -9,6 +9,7 @@
 // H/W pad and the nearest-2x upsample are index arithmetic in the A-tile gather - no padded or upsampled tensor is ever
 // materialised.  128 x BN x 32 tiles, LDS double buffer with register-staged prefetch (global loads of step k+1 are in
 // flight while step k computes), 16-byte-chunk XOR swizzle so ds_read_b128 fragment reads are conflict-free.
+#include <type_traits>
 #include "conv_kernels.h"
 
 namespace vlg {
@@ -257,6 +258,58 @@ constexpr size_t HT_LDS_BYTES = (size_t)(2 * HT_MAXROWS * 4 + 2 * 3 * 128 * 4) *
 // chunks - the same 64-byte patch rows and LDS image - on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak instead of a direct conv).
 // NWM: 32-row MFMA blocks per wave along the positions: 8 waves (4 x 2), each 64 x 64.  (Round 2 measured 16 waves of 32 x 64, 4 waves of
 // 128 x 64 and taps 1 / 2 as DPP lane shifts of tap 0's fragment: all slower; removed in round 3.)
+__device__ __attribute__((aligned(64))) const unsigned conv_zero_chunk[16] = {};   // the source of padding rows in conv_halo_kernel's LDS-DMA gather (64 B)
+
+#ifdef VLG_CONV_LAB
+// lab build only (tools/conv_lab.py): in-kernel phase stamps of every 61st workgroup - records of 24 x u64:
+// {Cin, Wo, kt, Q (steps), t_start, t_roles, t_prologue, t_loop, t_end, shader cycles at loop start, at loop end, -, stamps after
+// steps 0..11}; wall_clock64 = 100 MHz
+__device__ unsigned long long* conv_lab_buf = nullptr;
+__device__ unsigned conv_lab_count = 0;
+extern "C" int vlg_conv_lab_set(void* d_buf) {
+  unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(conv_lab_buf), &d_buf, sizeof(d_buf)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(conv_lab_count), &zero, sizeof(zero)) != hipSuccess;
+}
+extern "C" int vlg_conv_lab_count(unsigned* n) { return hipMemcpyFromSymbol(n, HIP_SYMBOL(conv_lab_count), sizeof(*n)) != hipSuccess; }
+#define LAB_STAMP(i)                                    \
+  do {                                                  \
+    if (lab_rec) lab_rec[i] = wall_clock64();           \
+  } while (0)
+#define LAB_CYCLES(i)                                        \
+  do {                                                       \
+    if (lab_rec) lab_rec[i] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define LAB_CYCLES(i) \
+  do {                \
+  } while (0)
+#define LAB_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+// timing ablations of the lab build (wrong results): -DVLG_CONV_LAB_NOW no weight loads in the loop, -DVLG_CONV_LAB_NOMFMA no fragment
+// reads / MFMAs, -DVLG_CONV_LAB_NOGATHER no patch gather in the loop, -DVLG_CONV_LAB_NOWST no weight LDS stores in the loop
+#ifdef VLG_CONV_LAB_NOW
+#define LAB_W_GLOAD(wr) do { } while (0)
+#else
+#define LAB_W_GLOAD(wr) w_gload(wr)
+#endif
+#ifdef VLG_CONV_LAB_NOWST
+#define LAB_W_LSTORE(wr, b) do { } while (0)
+#else
+#define LAB_W_LSTORE(wr, b) w_lstore(wr, b)
+#endif
+#ifdef VLG_CONV_LAB_NOMFMA
+#define LAB_COMPUTE(a, b, c) do { } while (0)
+#else
+#define LAB_COMPUTE(a, b, c) compute(a, b, c)
+#endif
+#ifdef VLG_CONV_LAB_NOGATHER
+#define LAB_HALO_DMA(a, b, c) do { } while (0)
+#else
+#define LAB_HALO_DMA(a, b, c) halo_dma(a, b, c)
+#endif
 template <typename T, int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
 __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
                                                                const float* __restrict__ bias, const T* __restrict__ residual,
@@ -280,6 +333,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   const int n0 = blockIdx.y * 128;
   const int taps = d.kt * 9;
   const int ncc = d.Cin / KC;
+#ifdef VLG_CONV_LAB
+  unsigned long long* lab_rec = nullptr;
+  if (conv_lab_buf != nullptr && tid == 0 && blockIdx.x % 61 == 7) {
+    const unsigned slot = atomicAdd(&conv_lab_count, 1u);
+    if (slot < 32768) {
+      lab_rec = conv_lab_buf + (size_t)slot * 24;
+      lab_rec[0] = d.Cin;
+      lab_rec[1] = d.Wo;
+      lab_rec[2] = d.kt;
+      lab_rec[3] = (unsigned long long)ncc * d.kt * 3;
+    }
+  }
+  LAB_STAMP(4);
+#endif
 
   // tile origin
   const int nTw = (d.Wo + HT_TW - 1) / HT_TW, nTh = (d.Ho + HT_TH - 1) / HT_TH, nTt = (d.To + HT_TT - 1) / HT_TT;
@@ -291,19 +358,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   const int t0 = (bid % nTt) * HT_TT;
   const int b = bid / nTt;
 
-  // patch gather roles: chunk e = tid + NTHR k  ->  patch row e >> 2, 16-byte chunk e & 3
+  // patch gather roles (LDS-DMA, global_load_lds_dwordx4: lane l of a wave writes LDS chunk base + l): LDS chunk slot e = tid + NTHR k
+  // holds patch row e >> 2; under the read-side swizzle that slot is the row's channel chunk (e & 3) ^ ((row >> 2) & 3)
   const int HF = HT_TT + d.kt - 1;
   const int nrows = HF * HT_HH * HT_HW;
   const int He = d.Hi << d.up, We = d.Wi << d.up;
   const uint4* in16 = reinterpret_cast<const uint4*>(in);
   long long hoff[HT_SLOTS];   // source chunk index (16-byte units) at channel chunk 0, -1 = zero padding, -2 = no such slot
-  int hslot[HT_SLOTS];
 #pragma unroll
   for (int k = 0; k < HT_SLOTS; ++k) {
     const int e = tid + NTHR * k;
-    const int hr = e >> 2, ch = e & 3;
+    const int hr = e >> 2, ch = (e & 3) ^ ((hr >> 2) & 3);
     hoff[k] = -2;
-    hslot[k] = 0;
     if (hr < nrows) {
       const int f = hr / (HT_HH * HT_HW), rem = hr - f * (HT_HH * HT_HW);
       const int y = rem / HT_HW, x = rem - y * HT_HW;
@@ -311,27 +377,37 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       ti = ti < 0 ? 0 : ti;                       // causal: frame 0 replicated in front (conv.py:126-129)
       ti = ti > d.Ti - 1 ? d.Ti - 1 : ti;         // frames past the end feed only rows that are never written
       const int uy = y0 + y - 1, ux = x0 + x - 1;
-      hslot[k] = hr * 4 + (ch ^ ((hr >> 2) & 3));
       hoff[k] = -1;
       if (uy >= 0 && ux >= 0 && uy < He && ux < We)
         hoff[k] = (((((long long)b * d.Ti + ti) * d.Hi + (uy >> d.up)) * d.Wi + (ux >> d.up)) * d.Cin) / EPV + ch;
     }
   }
-  uint4 hreg[HT_SLOTS];
-  auto halo_gload = [&](int cc) __attribute__((always_inline)) {
-    // unconditional loads (padding slots read chunk 0 of the tensor and are zeroed afterwards): a branch around a load makes
-    // hipcc drain the whole queue (vmcnt(0)) right behind it
+  // The gather goes global -> LDS without registers.  (Through registers, the loads sit behind a uniform branch - once per chunk -
+  // and hipcc joins the two paths with copies of the loaded registers, i.e. a wait for the loads right where they were issued: the
+  // in-kernel stamps of tools/conv_lab.py showed 3.0 instead of 1.3 us for every step that starts a gather.)  Padding slots copy a
+  // zero chunk.  The compiler does not see these loads: HALO_DMA_WAIT() before the barrier that publishes the patch; its own vmcnt
+  // waits for the weight registers only get stricter by loads it does not count.
+  const uint4* zero16 = reinterpret_cast<const uint4*>(conv_zero_chunk);
+  const unsigned lds0 = (unsigned)(uintptr_t)ht_smem;   // LDS byte address of the dynamic segment
+  // part / nparts: slot k goes out in call k % nparts of a chunk - one or two wave instructions per step instead of all of them in
+  // one (each touches 16 separate 64-byte pieces; a batch of seven holds the waves at the issue stage: stamps 3.0 vs 1.3 us per step)
+  int hpart[HT_SLOTS];   // uniform: the step of a chunk in which slot k goes out
 #pragma unroll
-    for (int k = 0; k < HT_SLOTS; ++k) hreg[k] = in16[(hoff[k] >= 0 ? hoff[k] : 0) + cc * 4];
+  for (int k = 0; k < HT_SLOTS; ++k) hpart[k] = k % (d.kt * 3 - 1);
+  auto halo_dma = [&](int cc, int buf, int part) __attribute__((always_inline)) {   // part < 0: every slot
 #pragma unroll
     for (int k = 0; k < HT_SLOTS; ++k)
-      if (hoff[k] < 0) hreg[k] = make_uint4(0, 0, 0, 0);
+      if (hoff[k] != -2 && (part < 0 || hpart[k] == part)) {
+        const uint4* src = hoff[k] >= 0 ? in16 + hoff[k] + cc * 4 : zero16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * (HT_MAXROWS * 4) + NTHR * k + wave * 64) * 16));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+      }
   };
-  auto halo_lstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < HT_SLOTS; ++k)
-      if (hoff[k] != -2) halo(buf)[hslot[k]] = hreg[k];
-  };
+#define HALO_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
@@ -430,24 +506,30 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   };
 
   // prologue: patch of chunk 0, weights of steps 0 and 1
-  halo_gload(0);
+  LAB_STAMP(5);
+  halo_dma(0, 0, -1);
   w_gload(wrA);
   w_gload(wrB);
-  halo_lstore(0);
   w_lstore(wrA, 0);
+  HALO_DMA_WAIT();
   __syncthreads();
+  LAB_STAMP(6);
+  LAB_CYCLES(9);
 
   int row = 0, cc = 0;   // compute iterator: row = a * 3 + i
   // MINE held step q's weights; they went to LDS during step q - 1, so the set is free for step q + 2.  (A macro, not a lambda
   // taking the sets by reference: hipcc keeps reference-passed register arrays in scratch.)
 #define VLG_HALO_STEP(q, MINE, NEXT)                                                        \
   do {                                                                                      \
-    if (row == 0 && cc + 1 < ncc) halo_gload(cc + 1);                                       \
-    w_gload(MINE); /* unconditional: a branch here makes every later wait a vmcnt(0) */     \
-    compute(halo(cc & 1), wts((q) & 1), ((row / 3) * HT_HH + (row % 3)) * HT_HW);           \
-    if (row == 1 && cc + 1 < ncc) halo_lstore((cc + 1) & 1);                                \
-    if ((q) + 1 < Q) w_lstore(NEXT, ((q) + 1) & 1);                                         \
+    LAB_W_GLOAD(MINE); /* unconditional: a branch here makes every later wait a vmcnt(0) */ \
+    LAB_COMPUTE(halo(cc & 1), wts((q) & 1), ((row / 3) * HT_HH + (row % 3)) * HT_HW);       \
+    if ((q) + 1 < Q) LAB_W_LSTORE(NEXT, ((q) + 1) & 1);                                     \
+    /* the next chunk's patch: a share per step (its buffer was last read before the chunk's first step), complete before the */      \
+    /* barrier of the chunk's last step */                                                                                            \
+    if (row < rows_per_chunk - 1 && cc + 1 < ncc) LAB_HALO_DMA(cc + 1, (cc + 1) & 1, row);  \
+    if (row == rows_per_chunk - 1) HALO_DMA_WAIT();                                         \
     __syncthreads();                                                                        \
+    if ((q) < 12) LAB_STAMP(12 + (q));                                                      \
     if (++row == rows_per_chunk) {                                                          \
       row = 0;                                                                              \
       ++cc;                                                                                 \
@@ -458,10 +540,67 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     if (q + 1 < Q) VLG_HALO_STEP(q + 1, wrB, wrA);
   }
 #undef VLG_HALO_STEP
+#undef HALO_DMA_WAIT
 #undef w_gload
 #undef w_lstore
+  LAB_STAMP(7);
+  LAB_CYCLES(10);
 
   // epilogue: + bias (+ residual) -> channels-last bf16 or planar fp32
+  if (out_cl != nullptr) {
+    // through LDS (free after the last step's barrier): the accumulator layout has one channel x 16 positions per lane, i.e. 2-byte
+    // stores 64 B apart (measured: 10-15 us per workgroup, a fifth of the Cin = 128 layers' time).  fp32 tile [256 positions][128 + 4],
+    // then every lane moves 16 bytes of consecutive channels: whole rows per 16 / 32 lanes for the residual read and the store.  The
+    // arithmetic is unchanged: (acc + bias) + residual in fp32, one rounding.
+    constexpr int LP = 128 + 4;
+    float* Ls = reinterpret_cast<float*>(ht_smem);
+    static_assert((size_t)256 * LP * sizeof(float) <= HT_LDS_BYTES, "epilogue tile fits the main loop's LDS");
+#pragma unroll
+    for (int mi = 0; mi < NWM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c = wave_n * 64 + ni * 32 + r32;
+        const float bv = bias ? bias[n0 + c] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = wave_m * (32 * NWM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          Ls[m * LP + c] = acc[mi][ni][e] + bv;
+        }
+      }
+    __syncthreads();
+    // 16 bytes of T per lane and access (8 bf16 / 4 fp32 channels): the tail is bound by the ISSUE of its global instructions
+    constexpr int CH = 16 / (int)sizeof(T), IPR = 128 / CH;   // channels per item, items per 128-channel row
+    constexpr int NIT = 256 * IPR / NTHR;
+    long long off[NIT];
+    uint4 rv[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + NTHR * k;
+      const int m = i / IPR, c0 = (i % IPR) * CH;
+      const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
+      off[k] = (t < d.To && y < d.Ho && x < d.Wo) ? ((((long long)b * d.To + t) * d.Ho + y) * d.Wo + x) * d.Cout + n0 + c0 : -1;
+    }
+    if (residual) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) rv[k] = *reinterpret_cast<const uint4*>(residual + (off[k] >= 0 ? off[k] : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + NTHR * k;
+      const float* lrow = Ls + (i / IPR) * LP + (i % IPR) * CH;
+      float vv[CH];
+#pragma unroll
+      for (int j = 0; j < CH; j += 4) *reinterpret_cast<float4*>(vv + j) = *reinterpret_cast<const float4*>(lrow + j);
+      uint4 ov;
+      T* oe = reinterpret_cast<T*>(&ov);
+      const T* re = reinterpret_cast<const T*>(&rv[k]);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) DT<T>::st(oe + j, residual ? vv[j] + DT<T>::ld(re + j) : vv[j]);
+      if (off[k] >= 0) *reinterpret_cast<uint4*>(out_cl + off[k]) = ov;
+    }
+    LAB_STAMP(8);
+    return;
+  }
   const long long pper = (long long)d.To * d.Ho * d.Wo;
 #pragma unroll
   for (int mi = 0; mi < NWM; ++mi) {
@@ -493,6 +632,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       }
     }
   }
+  LAB_STAMP(8);
 }
 
 static bool conv_halo_ok(const ConvDesc& d, int kc) {
