@@ -535,6 +535,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       ++cc;                                                                                 \
     }                                                                                       \
   } while (0)
+  // (a third register set = weights three steps ahead: measured, no gain - the wait for them is not what stretches a step)
   for (int q = 0; q < Q; q += 2) {
     VLG_HALO_STEP(q, wrA, wrB);
     if (q + 1 < Q) VLG_HALO_STEP(q + 1, wrB, wrA);
