@@ -39,6 +39,8 @@ z = torch.randn(4, 8, 5, 32, 32, device="cuda")
 vae.decode(z)
 torch.cuda.synchronize()
 buf = torch.zeros(32768 * 24, dtype=torch.int64, device="cuda")
+GAPS = len(sys.argv) > 1 and sys.argv[1] == "gaps"   # every workgroup of the Cin 128 / 256 x 256 / kt 3 layers: idle time of a CU between workgroups
+assert lib.vlg_conv_lab_mode(1 if GAPS else 0) == 0
 assert lib.vlg_conv_lab_set(ctypes.c_void_p(buf.data_ptr())) == 0
 vae.decode(z)
 torch.cuda.synchronize()
@@ -47,6 +49,21 @@ lib.vlg_conv_lab_count(ctypes.byref(n))
 assert lib.vlg_conv_lab_set(ctypes.c_void_p(0)) == 0
 rec = buf.cpu().numpy().reshape(-1, 24)[: min(n.value, 32768)]
 print(f"{n.value} records (10 ns ticks -> us)")
+if GAPS:
+    cus = defaultdict(list)
+    for r in rec:
+        hw, xcc = int(r[11]) & 0xFFFFFFFF, int(r[11]) >> 32
+        cus[(xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)].append((int(r[4]), int(r[8])))
+    gaps, durs = [], []
+    for v in cus.values():
+        v.sort()
+        for (s0, e0), (s1, e1) in zip(v, v[1:]):
+            if s1 - e0 < 5000:   # the same launch
+                gaps.append((s1 - e0) / 100.0)
+            durs.append((e0 - s0) / 100.0)
+    print(f"{len(cus)} CUs seen; workgroup (wave 0 start -> its last stamp): median {np.median(durs):.1f} us; "
+          f"gap to the next workgroup's wave 0 on the same CU: median {np.median(gaps):.2f} us, p10 {np.percentile(gaps, 10):.2f}, p90 {np.percentile(gaps, 90):.2f}")
+    sys.exit(0)
 groups = defaultdict(list)
 for r in rec:
     groups[(int(r[0]), int(r[1]), int(r[2]), int(r[3]))].append(r)

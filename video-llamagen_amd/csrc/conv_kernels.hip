@@ -266,6 +266,8 @@ __device__ __attribute__((aligned(64))) const unsigned conv_zero_chunk[16] = {};
 // steps 0..11}; wall_clock64 = 100 MHz
 __device__ unsigned long long* conv_lab_buf = nullptr;
 __device__ unsigned conv_lab_count = 0;
+__device__ int conv_lab_mode = 0;   // 1: every workgroup of the Cin 128 / 256-wide / kt 3 layers (gaps between workgroups on a CU)
+extern "C" int vlg_conv_lab_mode(int mode) { return hipMemcpyToSymbol(HIP_SYMBOL(conv_lab_mode), &mode, sizeof(mode)) != hipSuccess; }
 extern "C" int vlg_conv_lab_set(void* d_buf) {
   unsigned zero = 0;
   if (hipMemcpyToSymbol(HIP_SYMBOL(conv_lab_buf), &d_buf, sizeof(d_buf)) != hipSuccess) return 1;
@@ -310,14 +312,19 @@ extern "C" int vlg_conv_lab_count(unsigned* n) { return hipMemcpyFromSymbol(n, H
 #else
 #define LAB_HALO_DMA(a, b, c) halo_dma(a, b, c)
 #endif
-template <typename T, int HT_TT, int HT_TH>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
-__global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
+// WS (wave-specialised): 12 waves - waves 0..7 only read fragments and issue MFMAs, waves 8..11 (one per SIMD) do all the global
+// loads, LDS-DMA and weight LDS stores.  The stamps and ablations of tools/conv_lab.py: a step's memory instructions cost 0.45 us on
+// top of 0.96 us of fragment reads + MFMAs when they sit in the same instruction streams (each vector-memory instruction holds its
+// wave at the issue stage for 100+ cycles, MFMAs of that wave behind it); in waves of their own they run beside the MFMAs.
+template <typename T, int HT_TT, int HT_TH, bool WS>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
+__global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
                                                                const float* __restrict__ bias, const T* __restrict__ residual,
                                                                T* __restrict__ out_cl, float* __restrict__ out_planar) {
   constexpr int NWM = 2;
-  constexpr int NTHR = 1024 / NWM;           // 512 threads
-  constexpr int HT_SLOTS = ht_slots<NTHR>();
-  constexpr int WPT = 512 / NTHR;            // weight chunks per thread per tap: 128 rows x 4 chunks over the workgroup
+  constexpr int NTHR = 1024 / NWM;           // 512 MFMA threads
+  constexpr int NL = WS ? 256 : NTHR;        // threads that load
+  constexpr int HT_SLOTS = ht_slots<NL>();
+  constexpr int WPT = 512 / NL;              // weight chunks per loader thread per tap: 128 rows x 4 chunks over the loaders
   constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int KC = 4 * EPV;                // channels per chunk step: one 64-byte patch row
   static_assert(HT_TT * HT_TH * HT_TW == 256, "256 positions per tile");
@@ -328,14 +335,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   auto wts = [&](int buf) { return ht_smem + 2 * HT_MAXROWS * 4 + buf * (3 * 128 * 4); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const bool is_loader = !WS || tid >= NTHR;   // wave-uniform
+  const int ltid = WS ? tid - NTHR : tid, lwave = ltid >> 6;               // index among the loaders
+  const int wave_m = (wave >> 1) & 3, wave_n = wave & 1;
   const int r32 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.y * 128;
   const int taps = d.kt * 9;
   const int ncc = d.Cin / KC;
 #ifdef VLG_CONV_LAB
   unsigned long long* lab_rec = nullptr;
-  if (conv_lab_buf != nullptr && tid == 0 && blockIdx.x % 61 == 7) {
+  if (conv_lab_buf != nullptr && tid == 0 &&
+      (conv_lab_mode == 0 ? blockIdx.x % 61 == 7 : (d.Cin == 128 && d.Wo == 256 && d.kt == 3))) {
     const unsigned slot = atomicAdd(&conv_lab_count, 1u);
     if (slot < 32768) {
       lab_rec = conv_lab_buf + (size_t)slot * 24;
@@ -343,6 +353,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       lab_rec[1] = d.Wo;
       lab_rec[2] = d.kt;
       lab_rec[3] = (unsigned long long)ncc * d.kt * 3;
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      lab_rec[11] = ((unsigned long long)(xcc & 0xf) << 32) | hw;   // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
     }
   }
   LAB_STAMP(4);
@@ -367,10 +380,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   long long hoff[HT_SLOTS];   // source chunk index (16-byte units) at channel chunk 0, -1 = zero padding, -2 = no such slot
 #pragma unroll
   for (int k = 0; k < HT_SLOTS; ++k) {
-    const int e = tid + NTHR * k;
+    const int e = ltid + NL * k;
     const int hr = e >> 2, ch = (e & 3) ^ ((hr >> 2) & 3);
     hoff[k] = -2;
-    if (hr < nrows) {
+    if (is_loader && hr < nrows) {
       const int f = hr / (HT_HH * HT_HW), rem = hr - f * (HT_HH * HT_HW);
       const int y = rem / HT_HW, x = rem - y * HT_HW;
       int ti = t0 + f - (d.kt - 1);
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     for (int k = 0; k < HT_SLOTS; ++k)
       if (hoff[k] != -2 && (part < 0 || hpart[k] == part)) {
         const uint4* src = hoff[k] >= 0 ? in16 + hoff[k] + cc * 4 : zero16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * (HT_MAXROWS * 4) + NTHR * k + wave * 64) * 16));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * (HT_MAXROWS * 4) + NL * k + lwave * 64) * 16));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
   // (+ 64 rows for the second chunk of a 256-thread workgroup; with 1024 threads the upper half repeats the lower half's loads and stores)
-  const int wrow = (tid & 511) >> 2, wch = tid & 3;
+  const int wrow = (ltid & 511) >> 2, wch = ltid & 3;
   const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
   const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
   const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
@@ -450,6 +463,45 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
       wb_[2 * 512 + 256 + wslot] = wr##5;      \
     }                                          \
   } while (0)
+
+#define HALO_PATCH_SHARE(row, cc)                                                                                                     \
+  do {                                                                                                                                \
+    /* the next chunk's patch: a share per step (its buffer was last read before the chunk's first step), complete before the */      \
+    /* barrier of the chunk's last step */                                                                                            \
+    if ((row) < rows_per_chunk - 1 && (cc) + 1 < ncc) LAB_HALO_DMA((cc) + 1, ((cc) + 1) & 1, (row));                                  \
+    if ((row) == rows_per_chunk - 1) HALO_DMA_WAIT();                                                                                 \
+  } while (0)
+  if constexpr (WS) {
+    if (is_loader) {
+      // the loader waves' whole life: patch of chunk 0 and the weights of steps 0 and 1, then per step the weights two steps ahead
+      // into registers, the next step's weights registers -> LDS, a share of the next chunk's patch, the step's barrier
+      halo_dma(0, 0, -1);
+      w_gload(wrA);
+      w_gload(wrB);
+      w_lstore(wrA, 0);
+      HALO_DMA_WAIT();
+      __syncthreads();
+      int row = 0, cc = 0;
+#define VLG_LOADER_STEP(q, MINE, NEXT)                        \
+  do {                                                        \
+    LAB_W_GLOAD(MINE);                                        \
+    if ((q) + 1 < Q) LAB_W_LSTORE(NEXT, ((q) + 1) & 1);       \
+    HALO_PATCH_SHARE(row, cc);                                \
+    __syncthreads();                                          \
+    if (++row == rows_per_chunk) {                            \
+      row = 0;                                                \
+      ++cc;                                                   \
+    }                                                         \
+  } while (0)
+      for (int q = 0; q < Q; q += 2) {
+        VLG_LOADER_STEP(q, wrA, wrB);
+        if (q + 1 < Q) VLG_LOADER_STEP(q + 1, wrB, wrA);
+      }
+#undef VLG_LOADER_STEP
+      if (out_cl != nullptr) __syncthreads();   // the epilogue's barrier
+      return;
+    }
+  }
 
   // fragment roles
   int hb[NWM];
@@ -507,11 +559,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
 
   // prologue: patch of chunk 0, weights of steps 0 and 1
   LAB_STAMP(5);
-  halo_dma(0, 0, -1);
-  w_gload(wrA);
-  w_gload(wrB);
-  w_lstore(wrA, 0);
-  HALO_DMA_WAIT();
+  if constexpr (!WS) {
+    halo_dma(0, 0, -1);
+    w_gload(wrA);
+    w_gload(wrB);
+    w_lstore(wrA, 0);
+    HALO_DMA_WAIT();
+  }
   __syncthreads();
   LAB_STAMP(6);
   LAB_CYCLES(9);
@@ -521,13 +575,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
   // taking the sets by reference: hipcc keeps reference-passed register arrays in scratch.)
 #define VLG_HALO_STEP(q, MINE, NEXT)                                                        \
   do {                                                                                      \
-    LAB_W_GLOAD(MINE); /* unconditional: a branch here makes every later wait a vmcnt(0) */ \
-    LAB_COMPUTE(halo(cc & 1), wts((q) & 1), ((row / 3) * HT_HH + (row % 3)) * HT_HW);       \
-    if ((q) + 1 < Q) LAB_W_LSTORE(NEXT, ((q) + 1) & 1);                                     \
-    /* the next chunk's patch: a share per step (its buffer was last read before the chunk's first step), complete before the */      \
-    /* barrier of the chunk's last step */                                                                                            \
-    if (row < rows_per_chunk - 1 && cc + 1 < ncc) LAB_HALO_DMA(cc + 1, (cc + 1) & 1, row);  \
-    if (row == rows_per_chunk - 1) HALO_DMA_WAIT();                                         \
+    if constexpr (!WS) LAB_W_GLOAD(MINE); /* unconditional: a branch here makes every later wait a vmcnt(0) */                        \
+    LAB_COMPUTE(halo(cc & 1), wts((q) & 1), ((row / 3) * HT_HH + (row % 3)) * HT_HW);                                                 \
+    if constexpr (!WS) {                                                                                                              \
+      if ((q) + 1 < Q) LAB_W_LSTORE(NEXT, ((q) + 1) & 1);                                                                             \
+      HALO_PATCH_SHARE(row, cc);                                                                                                      \
+    }                                                                                                                                 \
     __syncthreads();                                                                        \
     if ((q) < 12) LAB_STAMP(12 + (q));                                                      \
     if (++row == rows_per_chunk) {                                                          \
@@ -541,6 +594,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     if (q + 1 < Q) VLG_HALO_STEP(q + 1, wrB, wrA);
   }
 #undef VLG_HALO_STEP
+#undef HALO_PATCH_SHARE
 #undef HALO_DMA_WAIT
 #undef w_gload
 #undef w_lstore
@@ -571,33 +625,36 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvDesc d, const T* __r
     __syncthreads();
     // 16 bytes of T per lane and access (8 bf16 / 4 fp32 channels): the tail is bound by the ISSUE of its global instructions
     constexpr int CH = 16 / (int)sizeof(T), IPR = 128 / CH;   // channels per item, items per 128-channel row
-    constexpr int NIT = 256 * IPR / NTHR;
-    long long off[NIT];
-    uint4 rv[NIT];
+    constexpr int NIT = 256 * IPR / NTHR, NB = NIT < 8 ? NIT : 8;   // batches of <= 8 items: registers (fp32 has 16 items)
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int i = tid + NTHR * k;
-      const int m = i / IPR, c0 = (i % IPR) * CH;
-      const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
-      off[k] = (t < d.To && y < d.Ho && x < d.Wo) ? ((((long long)b * d.To + t) * d.Ho + y) * d.Wo + x) * d.Cout + n0 + c0 : -1;
-    }
-    if (residual) {
+    for (int k0 = 0; k0 < NIT; k0 += NB) {
+      long long off[NB];
+      uint4 rv[NB];
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) rv[k] = *reinterpret_cast<const uint4*>(residual + (off[k] >= 0 ? off[k] : 0));
-    }
+      for (int k = 0; k < NB; ++k) {
+        const int i = tid + NTHR * (k0 + k);
+        const int m = i / IPR, c0 = (i % IPR) * CH;
+        const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
+        off[k] = (t < d.To && y < d.Ho && x < d.Wo) ? ((((long long)b * d.To + t) * d.Ho + y) * d.Wo + x) * d.Cout + n0 + c0 : -1;
+      }
+      if (residual) {
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int i = tid + NTHR * k;
-      const float* lrow = Ls + (i / IPR) * LP + (i % IPR) * CH;
-      float vv[CH];
+        for (int k = 0; k < NB; ++k) rv[k] = *reinterpret_cast<const uint4*>(residual + (off[k] >= 0 ? off[k] : 0));
+      }
 #pragma unroll
-      for (int j = 0; j < CH; j += 4) *reinterpret_cast<float4*>(vv + j) = *reinterpret_cast<const float4*>(lrow + j);
-      uint4 ov;
-      T* oe = reinterpret_cast<T*>(&ov);
-      const T* re = reinterpret_cast<const T*>(&rv[k]);
+      for (int k = 0; k < NB; ++k) {
+        const int i = tid + NTHR * (k0 + k);
+        const float* lrow = Ls + (i / IPR) * LP + (i % IPR) * CH;
+        float vv[CH];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) DT<T>::st(oe + j, residual ? vv[j] + DT<T>::ld(re + j) : vv[j]);
-      if (off[k] >= 0) *reinterpret_cast<uint4*>(out_cl + off[k]) = ov;
+        for (int j = 0; j < CH; j += 4) *reinterpret_cast<float4*>(vv + j) = *reinterpret_cast<const float4*>(lrow + j);
+        uint4 ov;
+        T* oe = reinterpret_cast<T*>(&ov);
+        const T* re = reinterpret_cast<const T*>(&rv[k]);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) DT<T>::st(oe + j, residual ? vv[j] + DT<T>::ld(re + j) : vv[j]);
+        if (off[k] >= 0) *reinterpret_cast<uint4*>(out_cl + off[k]) = ov;
+      }
     }
     LAB_STAMP(8);
     return;
@@ -735,7 +792,8 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       static bool attr_set = false;   // per instantiation of conv_forward<T>
       if (!attr_set) {
         hipError_t e = hipSuccess;
-        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8>)})
+        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, false>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, false>),
+                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, true>)})
           if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_LDS_BYTES);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
@@ -756,12 +814,19 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
           if (e) (void)hipEventRecord(e, s);
         }
       } stop{(e0 && e1) ? e1 : nullptr, st};
+      static const bool ws = getenv("VLG_CONV_WS") == nullptr || atoi(getenv("VLG_CONV_WS")) != 0;   // A/B knob: loader waves of their own
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
-        const long long tiles = (long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<T, 1, 8><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        const dim3 grid((unsigned)((long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW)), (unsigned)(d.Cout / 128));
+        if (ws)
+          conv_halo_kernel<T, 1, 8, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else
+          conv_halo_kernel<T, 1, 8, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       } else {
-        const long long tiles = (long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW);
-        conv_halo_kernel<T, 2, 4><<<dim3((unsigned)tiles, (unsigned)(d.Cout / 128)), 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        const dim3 grid((unsigned)((long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW)), (unsigned)(d.Cout / 128));
+        if (ws)
+          conv_halo_kernel<T, 2, 4, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+        else
+          conv_halo_kernel<T, 2, 4, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       }
       return VLG_OK;
     }
