@@ -371,6 +371,54 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   const int t0 = (bid % nTt) * HT_TT;
   const int b = bid / nTt;
 
+  // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
+  // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
+  // (+ 64 rows for the second chunk of a 256-thread workgroup; with 1024 threads the upper half repeats the lower half's loads and stores)
+  const int wrow = (ltid & 511) >> 2, wch = ltid & 3;
+  const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
+  const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
+  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
+  const int cin8 = d.Cin / EPV;   // 16-byte chunks per (cout, tap) weight row
+  const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
+  const int Q = ncc * rows_per_chunk;
+  int l_row = 0, l_cc = 0;   // load iterator: two steps ahead of the MFMAs
+  // two register sets as scalars (hipcc leaves uint4 arrays swapped between roles in scratch); 3..5 only with 256 threads
+  uint4 wrA0, wrA1, wrA2, wrA3, wrA4, wrA5, wrB0, wrB1, wrB2, wrB3, wrB4, wrB5;
+  wrA0 = wrA1 = wrA2 = wrA3 = wrA4 = wrA5 = wrB0 = wrB1 = wrB2 = wrB3 = wrB4 = wrB5 = make_uint4(0, 0, 0, 0);
+#define w_gload(wr)                                                                   \
+  do {                                                                                \
+    wr##0 = wbase[(size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];                         \
+    wr##1 = wbase[(size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];                         \
+    wr##2 = wbase[(size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];                         \
+    if constexpr (WPT == 2) {                                                         \
+      wr##3 = wbase[wrow2 + (size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];               \
+      wr##4 = wbase[wrow2 + (size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];               \
+      wr##5 = wbase[wrow2 + (size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];               \
+    }                                                                                 \
+    if (++l_row == rows_per_chunk) {                                                  \
+      l_row = 0;                                                                      \
+      if (++l_cc == ncc) l_cc = 0; /* past the end: reload a valid tile, unused */    \
+    }                                                                                 \
+  } while (0)
+#define w_lstore(wr, buf)                      \
+  do {                                         \
+    uint4* wb_ = wts(buf);                     \
+    wb_[0 * 512 + wslot] = wr##0;              \
+    wb_[1 * 512 + wslot] = wr##1;              \
+    wb_[2 * 512 + wslot] = wr##2;              \
+    if constexpr (WPT == 2) {                  \
+      wb_[0 * 512 + 256 + wslot] = wr##3;      \
+      wb_[1 * 512 + 256 + wslot] = wr##4;      \
+      wb_[2 * 512 + 256 + wslot] = wr##5;      \
+    }                                          \
+  } while (0)
+
+  // the weights of steps 0 and 1 are requested before the gather roles are worked out (a microsecond of integer arithmetic)
+  if (is_loader) {
+    w_gload(wrA);
+    w_gload(wrB);
+  }
+
   // patch gather roles (LDS-DMA, global_load_lds_dwordx4: lane l of a wave writes LDS chunk base + l): LDS chunk slot e = tid + NTHR k
   // holds patch row e >> 2; under the read-side swizzle that slot is the row's channel chunk (e & 3) ^ ((row >> 2) & 3)
   const int HF = HT_TT + d.kt - 1;
@@ -422,48 +470,6 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   };
 #define HALO_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-  // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
-  // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
-  // (+ 64 rows for the second chunk of a 256-thread workgroup; with 1024 threads the upper half repeats the lower half's loads and stores)
-  const int wrow = (ltid & 511) >> 2, wch = ltid & 3;
-  const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
-  const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
-  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
-  const int cin8 = d.Cin / EPV;   // 16-byte chunks per (cout, tap) weight row
-  const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
-  const int Q = ncc * rows_per_chunk;
-  int l_row = 0, l_cc = 0;   // load iterator: two steps ahead of the MFMAs
-  // two register sets as scalars (hipcc leaves uint4 arrays swapped between roles in scratch); 3..5 only with 256 threads
-  uint4 wrA0, wrA1, wrA2, wrA3, wrA4, wrA5, wrB0, wrB1, wrB2, wrB3, wrB4, wrB5;
-  wrA0 = wrA1 = wrA2 = wrA3 = wrA4 = wrA5 = wrB0 = wrB1 = wrB2 = wrB3 = wrB4 = wrB5 = make_uint4(0, 0, 0, 0);
-#define w_gload(wr)                                                                   \
-  do {                                                                                \
-    wr##0 = wbase[(size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];                         \
-    wr##1 = wbase[(size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];                         \
-    wr##2 = wbase[(size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];                         \
-    if constexpr (WPT == 2) {                                                         \
-      wr##3 = wbase[wrow2 + (size_t)(l_row * 3 + 0) * cin8 + l_cc * 4];               \
-      wr##4 = wbase[wrow2 + (size_t)(l_row * 3 + 1) * cin8 + l_cc * 4];               \
-      wr##5 = wbase[wrow2 + (size_t)(l_row * 3 + 2) * cin8 + l_cc * 4];               \
-    }                                                                                 \
-    if (++l_row == rows_per_chunk) {                                                  \
-      l_row = 0;                                                                      \
-      if (++l_cc == ncc) l_cc = 0; /* past the end: reload a valid tile, unused */    \
-    }                                                                                 \
-  } while (0)
-#define w_lstore(wr, buf)                      \
-  do {                                         \
-    uint4* wb_ = wts(buf);                     \
-    wb_[0 * 512 + wslot] = wr##0;              \
-    wb_[1 * 512 + wslot] = wr##1;              \
-    wb_[2 * 512 + wslot] = wr##2;              \
-    if constexpr (WPT == 2) {                  \
-      wb_[0 * 512 + 256 + wslot] = wr##3;      \
-      wb_[1 * 512 + 256 + wslot] = wr##4;      \
-      wb_[2 * 512 + 256 + wslot] = wr##5;      \
-    }                                          \
-  } while (0)
-
 #define HALO_PATCH_SHARE(row, cc)                                                                                                     \
   do {                                                                                                                                \
     /* the next chunk's patch: a share per step (its buffer was last read before the chunk's first step), complete before the */      \
@@ -476,8 +482,6 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
       // the loader waves' whole life: patch of chunk 0 and the weights of steps 0 and 1, then per step the weights two steps ahead
       // into registers, the next step's weights registers -> LDS, a share of the next chunk's patch, the step's barrier
       halo_dma(0, 0, -1);
-      w_gload(wrA);
-      w_gload(wrB);
       w_lstore(wrA, 0);
       HALO_DMA_WAIT();
       __syncthreads();
@@ -561,8 +565,6 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   LAB_STAMP(5);
   if constexpr (!WS) {
     halo_dma(0, 0, -1);
-    w_gload(wrA);
-    w_gload(wrB);
     w_lstore(wrA, 0);
     HALO_DMA_WAIT();
   }
@@ -610,6 +612,25 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
     constexpr int LP = 128 + 4;
     float* Ls = reinterpret_cast<float*>(ht_smem);
     static_assert((size_t)256 * LP * sizeof(float) <= HT_LDS_BYTES, "epilogue tile fits the main loop's LDS");
+    // 16 bytes of T per lane and access (8 bf16 / 4 fp32 channels): the tail is bound by the ISSUE of its global instructions
+    constexpr int CH = 16 / (int)sizeof(T), IPR = 128 / CH;   // channels per item, items per 128-channel row
+    constexpr int NIT = 256 * IPR / NTHR, NB = NIT < 8 ? NIT : 8;   // batches of <= 8 items: registers (fp32 has 16 items)
+    long long off[NB];
+    uint4 rv[NB];
+    auto load_batch = [&](int k0) __attribute__((always_inline)) {   // addresses of a batch and its residual values
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int i = tid + NTHR * (k0 + k);
+        const int m = i / IPR, c0 = (i % IPR) * CH;
+        const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
+        off[k] = (t < d.To && y < d.Ho && x < d.Wo) ? ((((long long)b * d.To + t) * d.Ho + y) * d.Wo + x) * d.Cout + n0 + c0 : -1;
+      }
+      if (residual) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) rv[k] = *reinterpret_cast<const uint4*>(residual + (off[k] >= 0 ? off[k] : 0));
+      }
+    };
+    load_batch(0);   // in flight while the accumulators go to LDS
 #pragma unroll
     for (int mi = 0; mi < NWM; ++mi)
 #pragma unroll
@@ -623,24 +644,9 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
         }
       }
     __syncthreads();
-    // 16 bytes of T per lane and access (8 bf16 / 4 fp32 channels): the tail is bound by the ISSUE of its global instructions
-    constexpr int CH = 16 / (int)sizeof(T), IPR = 128 / CH;   // channels per item, items per 128-channel row
-    constexpr int NIT = 256 * IPR / NTHR, NB = NIT < 8 ? NIT : 8;   // batches of <= 8 items: registers (fp32 has 16 items)
 #pragma unroll
     for (int k0 = 0; k0 < NIT; k0 += NB) {
-      long long off[NB];
-      uint4 rv[NB];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const int i = tid + NTHR * (k0 + k);
-        const int m = i / IPR, c0 = (i % IPR) * CH;
-        const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
-        off[k] = (t < d.To && y < d.Ho && x < d.Wo) ? ((((long long)b * d.To + t) * d.Ho + y) * d.Wo + x) * d.Cout + n0 + c0 : -1;
-      }
-      if (residual) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) rv[k] = *reinterpret_cast<const uint4*>(residual + (off[k] >= 0 ? off[k] : 0));
-      }
+      if (k0 > 0) load_batch(k0);
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const int i = tid + NTHR * (k0 + k);
@@ -814,7 +820,10 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
           if (e) (void)hipEventRecord(e, s);
         }
       } stop{(e0 && e1) ? e1 : nullptr, st};
-      static const bool ws = getenv("VLG_CONV_WS") == nullptr || atoi(getenv("VLG_CONV_WS")) != 0;   // A/B knob: loader waves of their own
+      // loader waves of their own: bf16 only (measured on the fp32 VQ-16 decode: 53.5 ms with them, 51.6 ms without - its 32x32x2 MFMAs
+      // leave the issue slots the loads need).  VLG_CONV_WS=0 / 1: A/B knob for both dtypes
+      static const int ws_knob = getenv("VLG_CONV_WS") ? atoi(getenv("VLG_CONV_WS")) : -1;
+      const bool ws = ws_knob < 0 ? sizeof(T) == 2 : ws_knob != 0;
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
         const dim3 grid((unsigned)((long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW)), (unsigned)(d.Cout / 128));
         if (ws)
