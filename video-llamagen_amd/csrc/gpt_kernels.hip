@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
   }
   // Slab store through LDS (the activation buffers are free after the loop's last barrier): the accumulator layout would write 64-byte
   // pieces (4 rows x 16 columns per wave instruction); the workgroup's 64 x 64 tile goes out as whole 256-byte rows instead - thread t
-  // writes 16 bytes, 16 threads cover a row (gemm_tall_kernel below does the same per wave).
+  // writes 16 bytes, 16 threads cover a row.
   float* cs = reinterpret_cast<float*>(&As[0][0]);   // [64 rows][64 columns], row pitch 68 floats: 17 KB of the 32 KB
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -320,129 +320,6 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const T* __restrict__ x,
       const int row = m0 + r0 + tr;
       const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cs + (r0 + tr) * 68 + tc);
       if (row < M) *reinterpret_cast<f32x4_t*>(slabs + ((size_t)split * M + row) * N + ncol0 + tc) = v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 64 rows x (64 NTW) columns per workgroup for ONE row block (32 < M <= 64: decode at 64 cache rows, BASELINE config 5).  In
-// gemm_wide_kernel every byte of weights is matched by a byte of activations through the compute unit's vector-memory pipe (64 x 64
-// tile), which holds about 64 KB of requests at a time: half of that window carries activations that every workgroup re-reads from L2,
-// and the weights stream at 2.4 TB/s.  Here a wave owns NTW 16-column tiles (NTW = 4: 256 columns per workgroup, 4 bytes of weights
-// per byte of activations), a whole K block of them (16 NTW KB per workgroup) is requested one block ahead into registers, and the
-// activation tile still goes through LDS once per workgroup.  One workgroup per compute unit in one round: columns x K slices are chosen
-// so that the grid is just above the CU count (gemm_plan).  Output: fp32 slabs, consumed by the reduce_* kernels (same rounding points).
-// ------------------------------------------------------------------------------------------------
-template <typename T, int NTW, bool FM>   // FM: w is the fragment-major copy (gpt_kernels.h: relayout_fragment_major)
-__global__ __launch_bounds__(256) void gemm_tall_kernel(const T* __restrict__ x, const T* __restrict__ w, float* __restrict__ slabs, int M,
-                                                        int N, int K) {
-  constexpr int KBLK = GemmT<T>::KBLK;   // 256 bytes per row per K block for both dtypes
-  __shared__ u32x4_t As[2][64 * 16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * (64 * NTW) + wave * (16 * NTW);
-  const int split = blockIdx.z, splits = gridDim.z;
-  const int nkb = K / KBLK;
-  constexpr int CPB = KBLK * (int)sizeof(T) / 16;   // 16-byte chunks per row per K block = 16
-
-  const u32x4_t* asrc[4];
-  int aslot[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int row = c >> 4, ch = c & 15;
-    const int gr = row < M ? row : M - 1;
-    asrc[i] = reinterpret_cast<const u32x4_t*>(x + (size_t)gr * K) + ch;
-    aslot[i] = row * 16 + (ch ^ (row & 15));
-  }
-  // weight chunk s2 of K block kb of tile nt: row-major = row (n0 + 16 nt + r), 16-byte chunk kb * 16 + 4 s2 + q;
-  // fragment-major = block (tile, K step 4 kb + s2), 16-byte slot `lane`
-  const u32x4_t* wsrc[NTW];
-  constexpr int WSTEP = FM ? 64 : 4;      // u32x4 units between the K steps of a block
-  constexpr int WBLK = FM ? 256 : CPB;    // ... between K blocks
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    if constexpr (FM)
-      wsrc[nt] = reinterpret_cast<const u32x4_t*>(w) + (size_t)(n0 / 16 + nt) * ((size_t)nkb * 256) + lane;
-    else
-      wsrc[nt] = reinterpret_cast<const u32x4_t*>(w + (size_t)(n0 + nt * 16 + r) * K) + q;
-  }
-
-  f32x4_t acc[NTW][4];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  u32x4_t ra[4], b[NTW][4], bn[NTW][4];
-  int kb = split;
-  if (kb < nkb) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kb * CPB];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) b[nt][s2] = __builtin_nontemporal_load(wsrc[nt] + (size_t)kb * WBLK + s2 * WSTEP);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) As[0][aslot[i]] = ra[i];
-  }
-  __syncthreads();
-  int buf = 0;
-  for (; kb < nkb; kb += splits) {
-    const int kn = kb + splits;
-    const bool more = kn < nkb;
-    const int kl = more ? kn : kb;   // unconditional loads (the last iteration re-reads its own block): counted waits stay exact
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = asrc[i][(size_t)kl * CPB];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) bn[nt][s2] = __builtin_nontemporal_load(wsrc[nt] + (size_t)kl * WBLK + s2 * WSTEP);
-    u32x4_t af[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int row = mt * 16 + r;
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) af[mt][s2] = As[buf][row * 16 + ((s2 * 4 + q) ^ (row & 15))];
-    }
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) mfma_block<T, 4>(af, b[nt], acc[nt]);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) As[buf ^ 1][aslot[i]] = ra[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) b[nt][s2] = bn[nt][s2];
-    buf ^= 1;
-  }
-  // Slab store.  The accumulator layout (lane = column r, rows q * 4 + e) would write 64-byte pieces - 4 rows x 16 columns per wave
-  // instruction, half cache lines again (an ablation without these stores: config 5 2.26 -> 2.08 s).  Each wave transposes its tile
-  // through its own LDS region, two n-tiles (32 columns = 128 bytes per row) at a time, and stores whole lines: lane l writes 16 bytes,
-  // 8 lanes cover a row, an instruction covers 8 rows x 128 bytes.
-  __shared__ float Cs[4][64 * 36];   // per wave [64 rows][32 columns], row pitch 36 floats (conflict-free writes, 16-byte aligned reads)
-  float* cw = Cs[wave];
-#pragma unroll
-  for (int p0 = 0; p0 < NTW; p0 += 2) {
-    const int ncols = (NTW - p0 >= 2) ? 32 : 16;
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      if (p0 + nn < NTW) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cw[(mt * 16 + q * 4 + e) * 36 + nn * 16 + r] = acc[p0 + nn][mt][e];
-      }
-    }
-    // same wave wrote and reads: LDS operations of a wave complete in order, no workgroup barrier needed
-    const int lanes_per_row = ncols / 4, rows_per_inst = 64 / lanes_per_row;
-    const int lr = lane / lanes_per_row, lc = (lane % lanes_per_row) * 4;
-    for (int r0 = 0; r0 < 64; r0 += rows_per_inst) {
-      const int row = r0 + lr;
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(cw + row * 36 + lc);
-      if (row < M) *reinterpret_cast<f32x4_t*>(slabs + ((size_t)split * M + row) * N + n0 + p0 * 16 + lc) = v;
     }
   }
 }
@@ -468,37 +345,18 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const T* __restrict__ x
 int gemm_max_splits() { return 8; }
 
 // launch geometry shared by gemm_slabs and the workspace sizing
-static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits, bool* wide = nullptr, int* tall = nullptr) {
+static void gemm_plan(int M, int N, int K, int kblk, bool& naive, int& mt, int& mchunks, int& splits, bool* wide = nullptr) {
   naive = (K % kblk != 0) || (N % 16 != 0);
   mt = M > 32 ? 4 : (M > 16 ? 2 : 1);
   mchunks = cdiv(M, mt * 16);
   splits = 1;
   if (wide) *wide = false;
-  if (tall) *tall = 0;
   if (naive) return;
   const int nkb = K / kblk;
   static const bool wide_off = getenv("VLG_GEMM_WIDE") != nullptr && atoi(getenv("VLG_GEMM_WIDE")) == 0;   // A/B knob
-  static const bool tall_off = getenv("VLG_GEMM_TALL") != nullptr && atoi(getenv("VLG_GEMM_TALL")) == 0;   // A/B knob
-  if (M > 32 && mchunks == 1 && !wide_off && !tall_off) {
-    // gemm_tall_kernel: the widest column tile (64 NTW) that divides N and still leaves every K slice >= 2 K blocks; K slices so that the
-    // grid is ONE round of workgroups on the 256 compute units (GPT-3B: qkv 50 tiles x 5, wo / w2 25 x 10, w13 68 x 3)
-    for (int ntw = 4; ntw >= 2; --ntw) {
-      if (N % (64 * ntw) != 0) continue;
-      const int tiles = N / (64 * ntw);
-      int sp = 256 / tiles;                    // one round: a compute unit with two workgroups would take twice as long as the others
-      // (one slice more where the round is under-filled - GPT-3B w13: 68 x 4 = 272 instead of 204 workgroups - measured slower: 2.32 vs 2.26 s)
-      if (sp > nkb / 2) sp = nkb / 2;
-      if (sp > gemm_max_splits()) sp = gemm_max_splits();   // the reduce_* kernels merge up to 8 slabs
-      if (sp < 1) sp = 1;
-      if (tiles * sp < 160) continue;          // too few workgroups to stream from: a narrower tile
-      splits = sp;
-      if (wide) *wide = true;
-      if (tall) *tall = ntw;
-      return;
-    }
-  }
   if (M > 32 && N % 64 == 0 && !wide_off) {   // gemm_wide_kernel: 64 x 64 tiles, K slices so that ~3 workgroups per CU stream
     if (wide) *wide = true;
+    // (measured on config 5 with 512 / 768 / 1024 / 1536 workgroups: 2.165 / 2.148 / 2.174 / 2.217 s)
     splits = 768 / ((N / 64) * mchunks);
     if (splits > nkb) splits = nkb;
     if (splits > gemm_max_splits()) splits = gemm_max_splits();
@@ -527,27 +385,12 @@ int gemm_slabs(const T* x, const T* w, float* ws, int M, int N, int K, int* spli
     return VLG_ERR_BAD_SHAPE;
   }
   bool naive, wide;
-  int mt, mchunks, splits, tall;
-  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits, &wide, &tall);
+  int mt, mchunks, splits;
+  gemm_plan(M, N, K, KBLK, naive, mt, mchunks, splits, &wide);
   if (naive) {
     const long long total = (long long)M * N;
     gemm_naive_kernel<T><<<dim3((unsigned)((total + 3) / 4)), 256, 0, st>>>(x, w, ws, M, N, K);
     *splits_out = 1;
-    return VLG_OK;
-  }
-  if (tall) {
-    const dim3 grid(N / (64 * tall), 1, splits);
-    static const bool fm_off = getenv("VLG_GEMM_FM") != nullptr && atoi(getenv("VLG_GEMM_FM")) == 0;   // A/B knob
-    if (wfm != nullptr && !fm_off) {
-      if (tall == 4) gemm_tall_kernel<T, 4, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
-      else if (tall == 3) gemm_tall_kernel<T, 3, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
-      else gemm_tall_kernel<T, 2, true><<<grid, 256, 0, st>>>(x, wfm, ws, M, N, K);
-    } else {
-      if (tall == 4) gemm_tall_kernel<T, 4, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
-      else if (tall == 3) gemm_tall_kernel<T, 3, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
-      else gemm_tall_kernel<T, 2, false><<<grid, 256, 0, st>>>(x, w, ws, M, N, K);
-    }
-    *splits_out = splits;
     return VLG_OK;
   }
   if (wide) {
