@@ -233,8 +233,9 @@ int vlg_vq_encode(vlg_vq_t* h, const float* d_x, int32_t B, int32_t Hh, int32_t 
  * d_z fp32 [n, dim] rows, d_codebook fp32 [n_codes, dim] -> int32 [n] (no normalisation)              */
 int vlg_codebook_argmin(const float* d_z, const float* d_codebook, int32_t n, int32_t n_codes, int32_t dim,
                         int32_t* d_idx, void* stream);
-/* (vlg_codebook_argmin / vlg_codebook_forward keep their code norms, usage histogram and partial sums in one process-wide scratch:
- *  call them from one stream at a time.)
+/* (vlg_codebook_argmin / vlg_codebook_forward keep their code norms, usage histogram and partial sums in scratch buffers owned by the
+ *  library, one set per stream: calls on one stream are ordered by it, calls on different streams or from different threads are
+ *  independent.)
  * Codebook.forward in eval mode, tokenizer_video/vqvae.py:161-209 (== CausalVideoVAE quant.py:42-96):
  * d_z fp32 [B, dim, n_pos] (the reference's [b, c, t, h, w] with n_pos = t*h*w), d_codebook fp32 [n_codes, dim] ->
  *   d_encodings        int32 [B, n_pos]        nearest code per position (first minimum)

@@ -156,3 +156,33 @@ def test_codebook_forward_vs_reference(golden):
     zb = torch.from_numpy(E).cuda()[torch.from_numpy(big).cuda()].permute(0, 4, 1, 2, 3).contiguous()
     rb = cb(zb)
     assert torch.equal(rb["encodings"].cpu(), torch.from_numpy(big)) and float(rb["commitment_loss"]) == 0.0
+
+
+def test_codebook_forward_on_two_streams():
+    """Two Codebook objects with different sizes driven from two streams at once (scratch buffers are per stream): the same results as
+    one after the other."""
+    import video_llamagen_amd as V
+    r = cases.rng(43)
+    specs = ((2048, 256, (2, 256, 2, 8, 8)), (1000, 64, (3, 64, 1, 9, 7)))
+    cbs, zs, want = [], [], []
+    for n_codes, dim, shape in specs:
+        E = r.standard_normal((n_codes, dim), dtype=np.float32)
+        cb = V.Codebook(n_codes, dim)
+        cb.load_state_dict({"embeddings": torch.from_numpy(E)})
+        z = torch.from_numpy(r.standard_normal(shape, dtype=np.float32)).cuda()
+        cbs.append(cb)
+        zs.append(z)
+        res = cb(z)
+        want.append({k: v.clone() for k, v in res.items()})
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for _ in range(20):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                got[i].append(cbs[i](zs[i]))
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        for res in got[i]:
+            for k in ("encodings", "embeddings", "commitment_loss", "perplexity"):
+                assert torch.equal(res[k], want[i][k]), (i, k)

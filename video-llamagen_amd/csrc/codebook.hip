@@ -17,6 +17,8 @@
 // range for both operands.  The epilogue applies the reference's rounding sequence fl(fl(zz - 2 dot) + ee), keeps a running
 // (min, first index) per row in registers, and the 32 lanes x 4 waves are merged by shuffles and LDS at the end.
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "conv_kernels.h"
 
@@ -219,12 +221,15 @@ __global__ __launch_bounds__(256) void codebook_stats_kernel(const double* __res
   }
 }
 
+// Scratch (code norms, histogram, partial sums) is kept per STREAM: calls on one stream are ordered by it and may share buffers, calls
+// on different streams - two Codebook objects, two threads - must not.  cb_mu covers the pool and a call's host side (enqueue only).
 struct CbScratch {
   DevBuf ee, idx, partial, hist;
 };
-CbScratch& cb_scratch() {
-  static CbScratch s;
-  return s;
+std::mutex cb_mu;
+CbScratch& cb_scratch(hipStream_t st) {   // under cb_mu; std::map keeps references valid across insertions
+  static std::map<hipStream_t, CbScratch> pool;
+  return pool[st];
 }
 
 }  // namespace
@@ -256,7 +261,8 @@ extern "C" int vlg_codebook_forward(const float* d_z, const float* d_codebook, i
   VLG_CHECK((d_embeddings_st != nullptr) == (d_loss_perplexity != nullptr), VLG_ERR_BAD_ARG,
             "vlg_codebook_forward: embeddings and loss/perplexity outputs come together");
   hipStream_t st = (hipStream_t)stream;
-  CbScratch& s = cb_scratch();
+  std::lock_guard<std::mutex> lk(cb_mu);
+  CbScratch& s = cb_scratch(st);
   const long long n = (long long)B * n_pos;
   const int nblk = (int)std::min<long long>(cdiv64(n, 256), 1024);
   if (s.ee.bytes < (size_t)n_codes * sizeof(float) || s.partial.bytes < (size_t)nblk * sizeof(double) || s.hist.bytes < (size_t)n_codes * sizeof(int)) {
@@ -283,7 +289,8 @@ extern "C" int vlg_codebook_argmin(const float* d_z, const float* d_codebook, in
   VLG_CHECK(d_z && d_codebook && d_idx && n > 0 && n_codes > 0 && dim > 0, VLG_ERR_BAD_ARG, "vlg_codebook_argmin: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (!codebook_mfma_ok(n_codes, dim)) return codebook_argmin(d_z, dim, 1, n, 0, d_codebook, n, n_codes, dim, false, d_idx, st);
-  CbScratch& s = cb_scratch();
+  std::lock_guard<std::mutex> lk(cb_mu);
+  CbScratch& s = cb_scratch(st);
   if (s.ee.bytes < (size_t)n_codes * sizeof(float)) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_TRY(s.ee.reserve((size_t)n_codes * sizeof(float)));
