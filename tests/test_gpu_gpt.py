@@ -656,6 +656,34 @@ def test_gpt_xl_full_size_first_tokens_vs_oracle():
         del m
 
 
+@pytest.mark.parametrize("hd,dts", [(32, ("fp32", "bf16")), (96, ("fp32", "bf16")), (128, ("fp32", "bf16")), (100, ("fp32",))])
+def test_prefill_attention_every_head_dim(hd, dts):
+    """prefill_attn_kernel (K / V of a (batch row, head) pair staged in LDS, one wave per condition row) at every head_dim the attention
+    is instantiated for - the golden cases have head_dim 64 only - against the oracle: 120 text tokens with ragged masks under guidance
+    (the padded keys of a row are dropped unless they are the row's own position), prefill + 2 decode steps.  (bf16 at head_dim 100:
+    rows are not a multiple of 16 bytes there, the per-row cache walk stays.)"""
+    import video_llamagen_amd as V
+    cfg = dict(cases.TINY_T2I, dim=2 * hd, n_head=2)
+    sd = detweights.gpt_weights(cfg)
+    c, mk = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[1, 57, 120])
+    tr_ref = {}
+    ref_ids = O.generate(O.GPTOracle(cfg, sd, "fp32"), c, 3, mk, cfg_scale=2.5, sample_logits=False, trace=tr_ref)
+    ref_lg = np.stack(tr_ref["logits"])
+    scale = max(1.0, np.abs(ref_lg).max())
+    for dt in dts:
+        m, unexpected = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16, sd=sd)
+        assert unexpected == []
+        ids, tr = V.generate(m, torch.from_numpy(c), 3, torch.from_numpy(mk), cfg_scale=2.5, sample_logits=False, return_trace=True)
+        lg = to_np(tr)
+        assert lg.shape == ref_lg.shape
+        if dt == "fp32":
+            np.testing.assert_allclose(lg, ref_lg, atol=3e-4 * scale, rtol=1e-4)     # fp32 accumulation-order noise through 2 layers
+            assert (ids.cpu().numpy() == ref_ids).all()
+        else:
+            assert np.abs(lg[0] - ref_lg[0]).max() < 6e-2 * scale                      # the prefill step, bf16 kernels vs the fp32 oracle
+        del m
+
+
 @pytest.mark.parametrize("name", ["GPT-B", "GPT-L", "GPT-XXL", "GPT-1B", "GPT-3B"])
 def test_every_model_width_fused_vs_slab_paths(name):
     """One layer at each published width (D 768 ... 3200, head_dim 64 and 100, F up to 8704), bf16, 8 classes with guidance (16 rows, the
