@@ -240,9 +240,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvDesc d, const T* __r
 // positions x 32 channels, <= 51 KB - into LDS ONCE per 32-channel chunk and walks the taps over it: the A fragment of tap
 // (a,i,j) is the same LDS image read at a row offset.  Per chunk: 45 KB of input + taps x 8 KB of weights for taps x 2.1 MFLOP
 // (212 FLOP per staged byte at 27 taps).  Weights: one kernel row (3 taps) per step, register prefetch two steps ahead, LDS
-// double buffer: 24 MFMAs per wave between barriers.  Padding (zero in
-// H/W, replicate-first-frame in T) and the nearest-2x upsample are resolved when the patch is gathered.
-// 512 threads = 8 waves (4 along positions x 2 along channels), each a 64 x 64 sub-tile of 32x32x16 MFMAs.
+// double buffer: 24 MFMAs per wave between barriers.  Padding (zero in H/W, replicate-first-frame in T) and the nearest-2x upsample are
+// resolved when the patch is gathered (LDS-DMA, a share per step).  8 MFMA waves (4 along positions x 2 along channels), each a 64 x 64
+// sub-tile of 32x32x16 MFMAs; bf16: + 4 loader waves (template parameter WS below).  The epilogue leaves through LDS as whole rows.
 // ---------------------------------------------------------------------------------------------------------------
 // Tile width 32: the 32 rows of one MFMA block are 32 consecutive patch rows (one output row of the tile), which is what makes the
 // ds_read_b128 A-fragment reads conflict-free under the (row >> 2) & 3 chunk swizzle for every tap offset - the instruction's four
