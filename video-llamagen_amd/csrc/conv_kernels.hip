@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
 
   // weight roles: row tid >> 2 of the 128-channel tile, chunk tid & 3, the three taps (a, i, 0..2) of one step; w is
   // [Cout][taps][Cin].  One step = one kernel row of taps = 24 MFMAs per wave per barrier.
-  // (+ 64 rows for the second chunk of a 256-thread workgroup; with 1024 threads the upper half repeats the lower half's loads and stores)
+  // (with 256 loader threads - WS - a thread also takes the row 64 further: WPT = 2)
   const int wrow = (ltid & 511) >> 2, wch = ltid & 3;
   const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
   const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
