@@ -186,3 +186,22 @@ def test_codebook_forward_on_two_streams():
         for res in got[i]:
             for k in ("encodings", "embeddings", "commitment_loss", "perplexity"):
                 assert torch.equal(res[k], want[i][k]), (i, k)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_causal_conv3d_halo_tile_planar_output(L, dt):
+    """vlg_causal_conv3d at shapes the halo-tile kernel takes (3x3x3 and 1x3x3, Cin a multiple of 32, Cout 128 / 256) with the entry
+    point's planar fp32 output: ragged tile edges (sizes that are not multiples of the 2 x 4 x 32 tile), nearest-2x upsampling in the
+    gather, several channel chunks - against the oracle's CausalConv3d.  bf16 runs the 12-wave form with loader waves."""
+    code = 0 if dt == "fp32" else 1
+    tol = 3e-5 if dt == "fp32" else 2e-2
+    r = cases.rng(47)
+    for (B, Cin, T, H, W, Cout, kt, up) in ((1, 64, 3, 5, 33, 128, 3, 0), (2, 32, 1, 9, 40, 256, 1, 0), (1, 96, 2, 3, 17, 128, 3, 1)):
+        x = r.standard_normal((B, Cin, T, H, W), dtype=np.float32)
+        w = (r.standard_normal((Cout, Cin, kt, 3, 3), dtype=np.float32) / np.sqrt(Cin * kt * 9)).astype(np.float32)
+        b = r.standard_normal((Cout,), dtype=np.float32)
+        got = _conv(L, x, w, b, up=up, dtype=code)
+        xu = x.repeat(2, axis=3).repeat(2, axis=4) if up else x
+        ref = O.causal_conv3d(xu, w, b, 1)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (B, Cin, T, H, W, Cout, kt, up, np.abs(got - ref).max())
