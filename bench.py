@@ -375,6 +375,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpt.status(sync=False)      # generate() is asynchronous; a device-side time-out in any timed step voids the number (raises)
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -559,18 +559,51 @@ def test_persistent_kernel_timeout_is_an_error_not_nan():
     good = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
     assert torch.isfinite(good).all()
     m.debug_spin_max = 1
+    m.check_faults = True                 # blocking form: wait for the call, raise at once
     with pytest.raises(_lib.VlgError) as ei:
         V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
     assert ei.value.code == _lib.VLG_ERR_STATE and "ran out" in str(ei.value)
-    # asynchronous form: the C call returns VLG_OK with the work enqueued, the fault is collected by status() - once
+    # asynchronous form (the default): the call returns with the work enqueued, the fault is collected by status() - once
     m.check_faults = False
     V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
     with pytest.raises(_lib.VlgError):
         m.status()
     m.status()
-    m.debug_spin_max, m.check_faults = 0, True
+    # ... or by the handle's next call, which refuses to start on top of an unreported fault
+    V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.VlgError):
+        V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    m.debug_spin_max = 0
     again = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5)
+    m.status()
     assert torch.equal(again, good)
+
+
+def test_pending_fault_makes_the_remaining_steps_return_at_once():
+    """A step of the persistent decode loop that times out leaves the fault word set; the N - 1 graph replays behind it were enqueued long
+    ago.  Each of them must see the word at entry and return immediately instead of spinning its own bound per wait (5119 steps x 1 s
+    would look like a hang): a forced time-out on a long generate comes back promptly, as VLG_ERR_STATE."""
+    import time
+    import video_llamagen_amd as V
+    from video_llamagen_amd import _lib
+    cfg = dict(cases.TINY_C2I, block_size=1024)
+    m, _ = product_gpt(cfg, torch.float32)
+    cls = torch.from_numpy(cases.class_ids(4, cfg["num_classes"]))
+    good = V.generate(m, cls, 1024, sample_logits=False)
+    m.status()
+    if m.counter("pd_steps") == 0:
+        pytest.skip("the persistent decode step does not cover this device")
+    m.debug_spin_max = 1
+    t0 = time.time()
+    V.generate(m, cls, 1024, sample_logits=False)
+    with pytest.raises(_lib.VlgError) as ei:
+        m.status()
+    assert ei.value.code == _lib.VLG_ERR_STATE
+    assert time.time() - t0 < 20.0
+    m.debug_spin_max = 0
+    assert torch.equal(V.generate(m, cls, 1024, sample_logits=False), good)
+    m.status()
 
 
 def test_full_width_decode_paths_agree():
@@ -714,7 +747,6 @@ def test_generate_is_stream_ordered_and_reuses_its_graph():
     kw = dict(cfg_scale=4.0, temperature=1.0, top_k=2000, top_p=1.0, seed=3)
     ref = V.generate(m, c, 256, **kw)
     torch.cuda.synchronize()
-    m.check_faults = False                # the Python mirror's default waits for the call to raise on device faults; the C call does not
     n0 = m.graphs_built()
     assert n0 >= 1
     side = torch.cuda.Stream()
@@ -936,3 +968,43 @@ def test_persistent_steps_of_two_handles_and_threads_do_not_starve_each_other():
     assert not errs, errs
     for i in range(2):
         assert len(got[i]) == 20 and all(torch.equal(o, want[i]) for o in got[i])
+
+
+def test_persistent_sampler_in_the_prefill_is_gated_too():
+    """The DiffLoss head runs its persistent sampler (every compute unit) already in the PREFILL - the head of token 0 - and a one-token
+    call (N = 1) is nothing but a prefill: the gate that chains persistent launches of one process on the device must be taken before it,
+    not only around the decode loop.  Two host threads, two handles, two streams: one issues one-token DiffLoss calls back to back, the other
+    full generates whose decode loop is the persistent step + the persistent sampler; every call must succeed (a starved grid ends in
+    VLG_ERR_STATE) and reproduce its single-threaded latents bit for bit."""
+    import threading
+    import video_llamagen_amd as V
+    ma, cfg, _ = _diff_model_w(torch.float32, 256, 10)
+    mb, _, _ = _diff_model_w(torch.float32, 256, 10)
+    ca, mka = cases.text_cond(6, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4])
+    cb, mkb = cases.text_cond(4, cfg["cls_token_num"], cfg["caption_dim"], lens=[3, 8, 1, 6], seed=9)
+    calls = [lambda: V.generate_t2v(ma, torch.from_numpy(ca), 1, torch.from_numpy(mka), seed=5),
+             lambda: V.generate_t2v(mb, torch.from_numpy(cb), 6, torch.from_numpy(mkb), seed=6)]
+    want = [f().cpu() for f in calls]
+    for m in (ma, mb):
+        m.status()
+    errs, got = [], [[], []]
+    go = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                go.wait()
+                for _ in range(30 if i == 0 else 10):
+                    got[i].append(calls[i]().cpu())
+                (ma, mb)[i].status()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert got[i] and all(torch.equal(o, want[i]) for o in got[i])

@@ -241,11 +241,8 @@ int codebook_argmin_mfma(const float* z, long long zs_row, long long zs_c, long 
                          float* ee_scratch, long long n, int n_e, int dim, int32_t* idx, hipStream_t st) {
   row_sumsq_kernel<<<cdiv(n_e, 4), 256, 0, st>>>(E, n_e, dim, ee_scratch);
   const size_t lds = ((size_t)64 * (dim + 4) + 64 + 256) * sizeof(float) + 256 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(codebook_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static LdsAttrOnce attr_once;
+  VLG_TRY(set_max_dynamic_lds(attr_once, {reinterpret_cast<const void*>(codebook_mfma_kernel)}, 160 * 1024));
   codebook_mfma_kernel<<<(unsigned)cdiv64(n, 64), 256, lds, st>>>(z, zs_row, zs_c, rows_per_batch, zs_batch, E, ee_scratch, n, n_e, dim, idx);
   VLG_HIP(hipGetLastError());
   return VLG_OK;

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <initializer_list>
 #include <map>
 #include <string>
 #include <vector>
@@ -37,6 +38,22 @@ void set_error(const char* fmt, ...);
       return code;                   \
     }                                \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel's code object, and a code object is loaded per DEVICE: a process-wide
+// "already set" flag leaves the second device of a process at the 64 KB default, and its launch then fails (or, unchecked, silently does
+// nothing).  `done` is one static array per call site (= per kernel instantiation).
+struct LdsAttrOnce {
+  bool done[64] = {};
+};
+inline int set_max_dynamic_lds(LdsAttrOnce& once, std::initializer_list<const void*> kernels, int bytes) {
+  int dev = 0;
+  VLG_HIP(hipGetDevice(&dev));
+  const bool track = dev >= 0 && dev < 64;
+  if (track && once.done[dev]) return VLG_OK;
+  for (const void* k : kernels) VLG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (track) once.done[dev] = true;
+  return VLG_OK;
+}
 
 // ---- storage dtypes -------------------------------------------------------------------------
 struct bf16 {

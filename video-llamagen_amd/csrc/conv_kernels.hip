@@ -795,18 +795,10 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
   {
     static const bool halo_off = getenv("VLG_CONV_HALO") != nullptr && atoi(getenv("VLG_CONV_HALO")) == 0;   // A/B knob
     if (!halo_off && conv_halo_ok(d, sizeof(T) == 2 ? 32 : 16)) {
-      static bool attr_set = false;   // per instantiation of conv_forward<T>
-      if (!attr_set) {
-        hipError_t e = hipSuccess;
-        for (const void* k : {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, false>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, false>),
-                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, true>)})
-          if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_LDS_BYTES);
-        if (e != hipSuccess) {
-          set_error("hipFuncSetAttribute(conv_halo_kernel, %zu B LDS): %s", HT_LDS_BYTES, hipGetErrorString(e));
-          return VLG_ERR_HIP;
-        }
-        attr_set = true;
-      }
+      static LdsAttrOnce attr_once;   // per instantiation of conv_forward<T>
+      VLG_TRY(set_max_dynamic_lds(attr_once, {reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, false>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, false>),
+                                              reinterpret_cast<const void*>(conv_halo_kernel<T, 2, 4, true>), reinterpret_cast<const void*>(conv_halo_kernel<T, 1, 8, true>)},
+                                  (int)HT_LDS_BYTES));
       const bool timed = conv_timer().on;
       hipEvent_t e0 = timed ? conv_timer_event() : nullptr, e1 = timed ? conv_timer_event() : nullptr;
       if (e0 && e1) {
@@ -1213,12 +1205,10 @@ __global__ __launch_bounds__(256) void spatial_attn_mfma_kernel(const bf16* __re
 template <int C>
 static int spatial_attention_mfma(const bf16* q, const bf16* k, const bf16* v, bf16* out, int NF, int HW, float scale, hipStream_t st) {
   const size_t lds = (size_t)32 * C * 2 + (size_t)C * 40 * 2 + (size_t)4 * 32 * 33 * 4 + (size_t)32 * 40 * 2 + 32 * 4;
-  static bool attr = false;
-  if (!attr) {
-    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spatial_attn_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  static LdsAttrOnce attr_once;   // per instantiation
+  VLG_TRY(set_max_dynamic_lds(attr_once, {reinterpret_cast<const void*>(spatial_attn_mfma_kernel<C>)}, 160 * 1024));
   spatial_attn_mfma_kernel<C><<<dim3((unsigned)cdiv(HW, 32), (unsigned)NF), 256, lds, st>>>(q, k, v, out, HW, scale);
+  VLG_HIP(hipGetLastError());
   return VLG_OK;
 }
 

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       }
     }
     if (tid < 16) bfin_s[tid] = tid < 2 * C ? DT<T>::ld(reinterpret_cast<const T*>(p.bf) + tid) : 0.f;
-    if (tid == 0) ok_sm = 1;
+    // a fault that is already pending (an earlier token's exchange timed out; the remaining tokens were enqueued long ago): this launch
+    // gives up at once instead of spinning each of its exchanges to the bound
+    if (tid == 0) ok_sm = (p.fault == nullptr || __hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) ? 1 : 0;
   }
 
   // ---- helpers ------------------------------------------------------------------------------------------------------------
@@ -506,7 +508,8 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   }
   __syncthreads();
 
-  bool alive = true;
+  bool alive = ok_sm != 0;   // uniform: read behind the barrier above
+  if (!alive) return;
   dp_u32x4_t bf[2][NKBW][4];     // hidden layers: two 16-column tiles (the streamed phases)
   dp_u32x4_t bff[1][NKBW][4];    // final layer: one tile of 2C <= 16 outputs, resident
   dp_u32x4_t wres[NRES > 0 ? NRES : 1][2][NKBW][4];

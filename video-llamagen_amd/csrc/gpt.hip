@@ -1197,13 +1197,15 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
     VLG_HIP(hipMemsetAsync(ln->kcache.p, 0, ln->kcache.bytes, r.st));
     VLG_HIP(hipMemsetAsync(ln->vcache.p, 0, ln->vcache.bytes, r.st));
   }
-  VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   hipStream_t s0 = r.st;
   const int steps = N - 1;
+  // The gate covers EVERY persistent launch of the call: the DiffLoss head runs its persistent sampler already in the prefill (the
+  // head of token 0), also when N == 1; the persistent decode step only runs in the decode loop.
   std::unique_lock<std::mutex> gate_lock;
   hipEvent_t gate_ev = nullptr;
   static const bool gate_off = getenv("VLG_PERSIST_GATE") != nullptr && atoi(getenv("VLG_PERSIST_GATE")) == 0;   // tests: show what the gate prevents
-  if (!gate_off && steps > 0 && (h->pdecode || (h->cfg.head == VLG_HEAD_HIDDEN && h->dl_persist_on))) {
+  const bool persist_head = h->cfg.head == VLG_HEAD_HIDDEN && h->dl_persist_on;
+  if (!gate_off && (persist_head || (steps > 0 && h->pdecode))) {
     int dev = 0;
     VLG_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64) {
@@ -1211,9 +1213,18 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
       gate_lock = std::unique_lock<std::mutex>(g.mu);
       if (!g.ev[dev]) VLG_HIP(hipEventCreateWithFlags(&g.ev[dev], hipEventDisableTiming));
       gate_ev = g.ev[dev];
-      VLG_HIP(hipStreamWaitEvent(s0, gate_ev, 0));   // the previous decode loop of this process on this device (any handle, any thread)
+      VLG_HIP(hipStreamWaitEvent(s0, gate_ev, 0));   // the previous call of this process on this device (any handle, any thread)
     }
   }
+  // an error between here and the record below must still record the event behind whatever was enqueued: the next holder waits on it
+  struct GateRelease {
+    hipEvent_t ev;
+    hipStream_t st;
+    ~GateRelease() {
+      if (ev) (void)hipEventRecord(ev, st);
+    }
+  } gate_release{gate_ev, s0};
+  VLG_TRY(r.prefill(d_cond, sp, d_noise, out_ids, out_lat, trace));
   if (steps > 0) {
     if (h->time_attn) {
       // eager loop; HIP events (on the launch stream) around layer 0's attention kernel
@@ -1301,6 +1312,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
   }
   if (gate_ev) {
     VLG_HIP(hipEventRecord(gate_ev, s0));
+    gate_release.ev = nullptr;
     gate_lock.unlock();
   }
   // ---- join back into the caller's stream ---------------------------------------------------------------------------

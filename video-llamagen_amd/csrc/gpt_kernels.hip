@@ -989,15 +989,13 @@ static int attn_launch(const T* qbuf, T* kc, T* vc, T* out, float* ws, const Ste
     const size_t lds = (size_t)2 * nk * (HD * sizeof(T) + 16) + (size_t)4 * HD * sizeof(float) + (size_t)4 * ((nk + 63) / 64 * 64) * sizeof(float);
     if (!pf_off && Tq > 1 && nk <= 128 && nk >= Tq && row_pos == nullptr && pages.table == nullptr && out_nks == 0 && (HD * sizeof(T)) % 16 == 0 &&
         lds <= 150 * 1024) {
-      static bool attr_set = false;   // per instantiation
-      if (!attr_set) {
-        VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefill_attn_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-      }
+      static LdsAttrOnce attr_once;   // per instantiation; the attribute itself is per device (common.h)
+      VLG_TRY(set_max_dynamic_lds(attr_once, {reinterpret_cast<const void*>(prefill_attn_kernel<T, HD>)}, 150 * 1024));
       if (ev0) (void)hipEventRecord(ev0, st);
       static const int z_knob = getenv("VLG_PREFILL_Z") ? atoi(getenv("VLG_PREFILL_Z")) : 0;   // A/B knob: workgroups per (b, h) pair
       const int zs = z_knob > 0 ? std::min(z_knob, 30) : 8;   // measured 1 / 2 / 4 / 8 on 32 x 120 and 8 x 120 rows: 8 is fastest on both (staging K / V again costs less than idle CUs)
       prefill_attn_kernel<T, HD><<<dim3(H, Bp, zs), 256, lds, st>>>(qbuf, kc, vc, out, state, Tq, H, S, nk, mask, Bmask, Tc, 1.0f / sqrtf((float)HD));
+      VLG_HIP(hipGetLastError());
       if (ev1) (void)hipEventRecord(ev1, st);
       return VLG_OK;
     }

@@ -180,9 +180,12 @@ __global__ __launch_bounds__(PD_NTHR) void pd_layers_kernel(PdArgs a) {
   const T* xg = reinterpret_cast<const T*>(a.x);
   const pd_layer_cptr layers_c = (pd_layer_cptr)(uintptr_t)a.layers;
 
-  if (tid == 0) flags[0] = 1;
+  // A fault word that is already set (an earlier step of this call timed out, and the host has enqueued the remaining steps long ago): leave
+  // at once instead of spinning every wait of every remaining step to its bound - the call is lost either way (vlg_gpt_status).
+  if (tid == 0) flags[0] = (a.fault == nullptr || __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) ? 1 : 0;
   for (unsigned i = tid; i < 16u * MT * a_stride / 16; i += PD_NTHR) reinterpret_cast<pd_u32x4_t*>(As)[i] = pd_u32x4_t{0u, 0u, 0u, 0u};
   pd_barrier();
+  if (flags[0] == 0) return;
 
   // ---- work assignment (one tile or unit per workgroup and phase: pd_ok) -------------------------------------------------------------
   // QKV: 16-column tile wg of wqkv.  W13: f-tile wg of [w1; w3].  WO / W2: the D / 16 output tiles are cut into `ksplit` K slices so that

@@ -355,16 +355,8 @@ int sample_rows(const float* logits, int B, int V, bool cfg_on, const vlg_sampli
   const bool topp = sp.top_p < 1.0f;
   if (topp) {
     const size_t dyn = (size_t)VMAX * 8 + NT * 8 + VMAX / 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(sample_kernel) failed: %s", hipGetErrorString(e));
-        return VLG_ERR_HIP;
-      }
-      attr_set = true;
-    }
+    static LdsAttrOnce attr_once;
+    VLG_TRY(set_max_dynamic_lds(attr_once, {reinterpret_cast<const void*>(&sample_kernel<true>)}, (int)dyn));
     sample_kernel<true><<<B, NT, dyn, st>>>(logits, B, V, cfg_on ? 1 : 0, sp.cfg_scale, sp.cfg_interval, sp.temperature, sp.top_k,
                                             sp.top_p, sp.sample_logits, sp.seed, noise, state, fixed_step, N, out_ids, cur_tok, trace,
                                             probs, b_off, B_total, row_step);

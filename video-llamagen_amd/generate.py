@@ -75,11 +75,11 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
                                          C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
                                          L.stream_ptr(dev)))
-        # The C call returns with the work enqueued (include/vlg.h).  The persistent kernels bound their in-launch waits and report a
-        # wait that ran out through the handle's fault word: by default the mirror waits for the call and raises VlgError instead of
-        # handing out the poisoned results; model.check_faults = False keeps the call asynchronous (the fault then surfaces on the
-        # next call, or through model.status()).
-        if getattr(model, "check_faults", True):
+        # The C call returns with the work enqueued (include/vlg.h), and so does this mirror: like any torch op the result tensor is
+        # ordered on the current stream.  The persistent kernels bound their in-launch waits and report a wait that ran out through the
+        # handle's fault word; that surfaces as VlgError(VLG_ERR_STATE) on the handle's next call or through model.status() (which the
+        # sample scripts call before they write files).  model.check_faults = True waits for this call and raises at once instead.
+        if getattr(model, "check_faults", False):
             L.check(L.lib().vlg_gpt_status(model._handle, C.c_int32(1)))
     return (out_lat if latent else out_ids), trace_d
 

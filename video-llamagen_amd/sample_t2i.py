@@ -55,6 +55,7 @@ def main(args):
             return vq_model.decode_code(index_sample, qzshape)
 
     samples = vd.sharded_call(run, [c_indices, c_emb_masks], args.num_samples)
+    gpt_model.status()        # generate() is asynchronous: a device-side time-out of a persistent kernel surfaces here, before anything is written
     if is_rank0():
         save_images(samples, args.out)
         print("image is saved to %s.npy" % args.out)

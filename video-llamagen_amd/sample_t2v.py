@@ -45,6 +45,7 @@ def main(args):
         return (((x + 1) / 2) * 255).to(torch.uint8).permute(0, 2, 3, 4, 1).contiguous()   # [B,T,H,W,3]
 
     videos = vd.sharded_call(run, [cond, masks], args.num_samples)
+    gpt_model.status()        # generate() is asynchronous: a device-side time-out of a persistent kernel surfaces here, before anything is written
     if is_rank0():
         np.save(args.out + ".npy", videos.cpu().numpy())
         print("videos %s saved to %s.npy" % (tuple(videos.shape), args.out))
