@@ -153,6 +153,12 @@ int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value);
  * != 1 treats rows [0, B/2) of the batch as the conditional and rows [B/2, B) as the unconditional half of every pair (b, b + B/2): one
  * x_T draw per pair, the network sees the conditional half's x_t twice, eps = u + cfg (c - u); B must be even.                        */
 int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value);
+/* Teacher forcing for evaluation (per-step outputs at positions far into a sequence, without the chaos of a free-running trajectory): while
+ * set, the input of decode step i + 1 is forced[b][i] - int32 ids [B][N] for the token heads, fp32 latents [B][N][C] for the latent heads;
+ * device memory, caller-owned, alive until cleared - instead of what the head produced at step i; d_out_* and d_trace of vlg_gpt_generate
+ * still receive the model's OWN output of every step.  This is the inference-side form of the reference's teacher-forced forward
+ * (autoregressive/models/gpt.py:334-347: `idx[:, :-1]` as inputs, targets beside it; gpt_video.py:404-431 for latents).  Both null: off.  */
+int vlg_gpt_set_teacher(vlg_gpt_t* h, const int32_t* d_forced_ids, const float* d_forced_latents);
 /* Device-side faults.  The persistent kernels of this handle (the DiffLoss sampler, the persistent decode step) exchange data between
  * workgroups inside one launch and bound every wait; a wait that runs out (the grid was not fully resident because something else held
  * compute units, or option "debug_spin_max" forced it) records a fault word in host-visible memory and the kernel drains.  Results of

@@ -75,7 +75,7 @@ def apply_rope(x, fc, dt):
 # primitives
 # ----------------------------------------------------------------------------
 def linear(x, w, dt, b=None):
-    y = x.astype(F32) @ w.T.astype(F32)
+    y = np.asarray(x, dtype=F32) @ np.asarray(w, dtype=F32).T          # no copies: BLAS takes the transposed view
     if b is not None:
         y = y + b
     return rt(y, dt)
@@ -178,11 +178,14 @@ class GPTOracle:
         xq, xk, xv = (t.transpose(0, 2, 1, 3) for t in (xq, xk, xv))
         self.k_cache[li][:B, :, input_pos] = xk                                          # gpt.py:177-185
         self.v_cache[li][:B, :, input_pos] = xv
-        keys, vals = self.k_cache[li][:B], self.v_cache[li][:B]
-        sc = np.einsum("bhqd,bhsd->bhqs", xq.astype(F32), keys) * F32(1.0 / math.sqrt(hd))  # gpt.py:233
-        sc = np.where(mask[:, None], sc, F32(-np.inf))
+        # The reference attends over ALL S cache rows (gpt.py:230-237); rows beyond the newest position are masked to -inf, i.e. they
+        # get probability exactly 0 and add exactly 0 to P V: dropping them changes no value, only the time a long test takes.
+        kmax = int(np.max(input_pos)) + 1
+        keys, vals = self.k_cache[li][:B, :, :kmax], self.v_cache[li][:B, :, :kmax]
+        sc = np.matmul(xq.astype(F32), keys.transpose(0, 1, 3, 2)) * F32(1.0 / math.sqrt(hd))  # gpt.py:233
+        sc = np.where(mask[:, None, :, :kmax], sc, F32(-np.inf))
         p = softmax_lastdim(sc)
-        o = rt(np.einsum("bhqs,bhsd->bhqd", p, vals), dt)
+        o = rt(np.matmul(p, vals), dt)
         o = o.transpose(0, 2, 1, 3).reshape(B, q, D)
         return linear(o, sd[f"layers.{li}.attention.wo.weight"], dt)
 
@@ -282,9 +285,11 @@ def build_mask(model, T, emb_masks, cfg_on):
 
 
 def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1,
-             temperature=1.0, top_k=0, top_p=1.0, sample_logits=True, noise=None, trace=None):
+             temperature=1.0, top_k=0, top_p=1.0, sample_logits=True, noise=None, trace=None, teacher=None):
     """Discrete-token generate (generate.py:127-180).  noise: [N,B,V] Exp(1) or None.
-    trace (optional dict) receives per-step combined logits margins."""
+    trace (optional dict) receives per-step combined logits margins.
+    teacher (optional int [B, N]): teacher forcing, the inference-side form of the reference's training forward (gpt.py:334-347) -
+    the input of step i + 1 is teacher[:, i]; the returned ids stay the model's own samples."""
     cond = np.asarray(cond)
     cfg_on = cfg_scale > 1.0
     if model.model_type == "c2i":
@@ -315,6 +320,8 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
     for i in range(max_new_tokens - 1):
         if cfg_interval > -1 and i > cfg_interval:
             cfg_flag = False
+        if teacher is not None:
+            tok = np.asarray(teacher)[:, i].astype(tok.dtype)
         x = np.concatenate([tok, tok]) if cfg_on else tok
         logits = model.forward(idx=x[:, None], input_pos=np.array([T + i]))[:, -1]
         if cfg_on:
@@ -326,11 +333,13 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
     return seq
 
 
-def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1):
+def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, teacher=None):
     """Continuous-latent generate with the adapter2 (MSE) head: skeleton of
     generate_video_diff.py:185-228 with sample() = identity (:57-60) and the head of
     gpt_video.py:431; CFG combine on the output embeddings as in the commented block
-    generate_video_diff.py:97-105 (the shipped code runs cfg_scale=1 only)."""
+    generate_video_diff.py:97-105 (the shipped code runs cfg_scale=1 only).
+    teacher (optional float [B, N, C]): teacher forcing as in the reference's training forward (gpt_video.py:404-431, the ground-truth
+    latents as inputs) - step i + 1 is fed teacher[:, i]; the returned latents stay the model's own outputs."""
     cfg_on = cfg_scale > 1.0
     assert model.model_type == "t2v"
     if cfg_on:
@@ -353,6 +362,8 @@ def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg
     for i in range(max_new_tokens - 1):
         if cfg_interval > -1 and i > cfg_interval:
             cfg_flag = False
+        if teacher is not None:
+            e = np.asarray(teacher, F32)[:, i]
         x = np.concatenate([e, e]) if cfg_on else e
         e = model.forward(latent=x[:, None, :], input_pos=np.array([T + i]))[:, -1]
         if cfg_on:

@@ -71,6 +71,8 @@ struct vlg_gpt {
   int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured rule of pd_use())
   bool weights_fm = true;            // stream the fragment-major weight copies (option "weights_fm"; results are bit-identical either way)
   bool act_fm = true;                // keep the fused decode chain's activations A-fragment-major (option "act_fm"; bit-identical either way)
+  const int32_t* teach_ids = nullptr;   // vlg_gpt_set_teacher: forced inputs [B][N] (token heads) ...
+  const float* teach_lat = nullptr;     //   ... or [B][N][C] fp32 (latent heads); caller-owned device memory
   int pos_offset = 0;                // benchmarks ("debug_pos_offset"): decode as if this many tokens had already been generated (zeroed cache rows)
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool pd_fm = false;                // ... which are the fragment-major copies
@@ -443,6 +445,16 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
   }
   set_error("unknown option %s", key);
   return VLG_ERR_BAD_ARG;
+}
+
+extern "C" int vlg_gpt_set_teacher(vlg_gpt_t* h, const int32_t* d_ids, const float* d_latents) {
+  VLG_CHECK(h, VLG_ERR_BAD_ARG, "vlg_gpt_set_teacher: null handle");
+  VLG_CHECK(!(d_ids && d_latents), VLG_ERR_BAD_ARG, "vlg_gpt_set_teacher: ids or latents, not both");
+  if (d_ids) VLG_CHECK(h->cfg.head == VLG_HEAD_LOGITS, VLG_ERR_BAD_ARG, "vlg_gpt_set_teacher: forced ids need a token head");
+  if (d_latents) VLG_CHECK(h->cfg.head != VLG_HEAD_LOGITS, VLG_ERR_BAD_ARG, "vlg_gpt_set_teacher: forced latents need a latent head");
+  h->teach_ids = d_ids;
+  h->teach_lat = d_latents;
+  return VLG_OK;
 }
 
 // a pending device-side fault (time-out inside a persistent kernel): report + clear
@@ -1039,7 +1051,14 @@ struct Runner {
       VLG_TRY(layers(1, S - 1));
       VLG_TRY(head(ln->xn.as<T>(), sp, noise, out_ids, out_lat, trace));
     }
+    VLG_TRY(teacher());
     return advance_state(state(), st);
+  }
+  // teacher forcing (vlg_gpt_set_teacher): behind the head, in front of the state advance
+  int teacher() {
+    if (h->teach_ids == nullptr && h->teach_lat == nullptr) return VLG_OK;
+    return force_next_input(state(), h->teach_ids, h->teach_lat, ln->cur_tok.as<int32_t>(), h->C > 0 ? ln->cur_lat.as<float>() : nullptr, B, Bp,
+                            h->C > 0 ? h->C : 1, N, b0, st);
   }
 
   // one iteration of the request scheduler: every row at its own position (StepState::row_pos / row_step), inputs per row_cls
@@ -1077,6 +1096,7 @@ struct Runner {
       hl = ln->hl.as<T>();
     }
     VLG_TRY(head(hl, sp, noise, out_ids, out_lat, trace));
+    VLG_TRY(teacher());   // state->step is 0 here: the first decode step is fed forced[:, 0]
     return set_state(state(), Tc + h->pos_offset, 1, st);   // pos_offset > 0: the rows in between are zero (generate_impl)
   }
 };
@@ -1277,7 +1297,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
                                    (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
-                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset, (uint64_t)((h->weights_fm ? 1 : 0) | (h->act_fm ? 2 : 0))};
+                                   (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset, (uint64_t)(uintptr_t)h->teach_ids, (uint64_t)(uintptr_t)h->teach_lat, (uint64_t)((h->weights_fm ? 1 : 0) | (h->act_fm ? 2 : 0))};
       {
         const auto pk = ln->ptr_key();
         key.insert(key.end(), pk.begin(), pk.end());

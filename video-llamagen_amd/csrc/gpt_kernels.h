@@ -298,6 +298,9 @@ int pd_layers(PdArgs a, hipStream_t st);
 
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
+// teacher forcing: cur_tok [Bp] / cur_lat [B][C] <- ids [B_total][N] / lat [B_total][N][C] at token index state->step (rows b_off..)
+int force_next_input(const StepState* state, const int32_t* ids, const float* lat, int32_t* cur_tok, float* cur_lat, int B, int Bp, int C, int N,
+                     int b_off, hipStream_t st);
 template <typename T>
 int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok,
                         const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks = 0);   // row_cls: >= 0 class id, -3 pending row, else token; out_nks > 0: out is A-fragment-major

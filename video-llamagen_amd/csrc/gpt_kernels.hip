@@ -1339,4 +1339,22 @@ int set_state(StepState* state, int pos, int step, hipStream_t st) {
   return VLG_OK;
 }
 
+// Teacher forcing (vlg_gpt_set_teacher): the input of the NEXT step becomes the caller's token / latent for the step just produced
+// (state->step, read on the device so that the captured graph replays), whatever the head sampled.  The head's own outputs stay in place.
+__global__ void force_next_input_kernel(const StepState* s, const int32_t* ids, const float* lat, int32_t* cur_tok, float* cur_lat, int B, int Bp,
+                                        int C, int N, int b_off) {
+  const int step = s->step;
+  if (step >= N) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ids != nullptr && i < Bp) cur_tok[i] = ids[(size_t)(b_off + i % B) * N + step];   // rows b and b + B (guidance) are fed the same token: generate.py:92
+  if (lat != nullptr && i < B * C) cur_lat[i] = lat[((size_t)(b_off + i / C) * N + step) * C + i % C];
+}
+int force_next_input(const StepState* state, const int32_t* ids, const float* lat, int32_t* cur_tok, float* cur_lat, int B, int Bp, int C, int N,
+                     int b_off, hipStream_t st) {
+  const int n = lat != nullptr ? std::max(Bp, B * C) : Bp;
+  force_next_input_kernel<<<cdiv(n, 256), 256, 0, st>>>(state, ids, lat, cur_tok, cur_lat, B, Bp, C, N, b_off);
+  VLG_HIP(hipGetLastError());
+  return VLG_OK;
+}
+
 }  // namespace vlg

@@ -19,7 +19,7 @@ def _params(cfg_scale, cfg_interval, temperature=1.0, top_k=0, top_p=1.0, sample
                             seed=int(seed))
 
 
-def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, trace, sampling_kwargs, cfg_iter=1.0):
+def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, trace, sampling_kwargs, cfg_iter=1.0, teacher=None):
     model._ensure_handle()
     dev = model._device
     B = cond.shape[0]
@@ -53,6 +53,11 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
     trace_d = None
     if trace:
         trace_d = torch.empty((max_new_tokens, B, width), dtype=torch.float32, device=dev)
+    teach_d = None
+    if teacher is not None:   # teacher forcing (include/vlg.h vlg_gpt_set_teacher): step i + 1 is fed teacher[:, i]; outputs stay the model's own
+        want = (B, max_new_tokens, width) if latent else (B, max_new_tokens)
+        assert tuple(teacher.shape) == want, (tuple(teacher.shape), want)
+        teach_d = teacher.to(device=dev, dtype=torch.float32 if latent else torch.int32).contiguous()
     out_ids = out_lat = None
     if latent:
         out_lat = torch.empty((B, max_new_tokens, width), dtype=torch.float32, device=dev)
@@ -72,9 +77,15 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_spin_max", C.c_int64(int(getattr(model, "debug_spin_max", 0)))))
         if latent and model._head_code() == L.VLG_HEAD_HIDDEN:
             L.check(L.lib().vlg_gpt_set_option_f64(model._handle, b"cfg_iter", C.c_double(float(cfg_iter))))
-        L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
-                                         C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
-                                         L.stream_ptr(dev)))
+        L.check(L.lib().vlg_gpt_set_teacher(model._handle, L.ptr(None if latent else teach_d), L.ptr(teach_d if latent else None)))
+        try:
+            L.check(L.lib().vlg_gpt_generate(model._handle, L.ptr(cond_d), L.ptr(mask_d), C.c_int32(B), C.c_int32(max_new_tokens),
+                                             C.byref(sp), L.ptr(noise_d), L.ptr(out_ids), L.ptr(out_lat), L.ptr(trace_d),
+                                             L.stream_ptr(dev)))
+        finally:
+            if teach_d is not None:
+                L.check(L.lib().vlg_gpt_set_teacher(model._handle, None, None))
+                teach_d.record_stream(torch.cuda.current_stream(dev))   # the enqueued steps still read it
         # The C call returns with the work enqueued (include/vlg.h), and so does this mirror: like any torch op the result tensor is
         # ordered on the current stream.  The persistent kernels bound their in-launch waits and report a wait that ran out through the
         # handle's fault word; that surfaces as VlgError(VLG_ERR_STATE) on the handle's next call or through model.status() (which the
@@ -86,25 +97,27 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
 
 @torch.no_grad()
 def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, noise=None, return_trace=False,
-             **sampling_kwargs):
+             teacher=None, **sampling_kwargs):
     """Returns int32 [B, max_new_tokens] (generate.py:168,180).  Extra (non-reference) keywords: `noise`
-    ([N,B,V] Exp(1) draws so that results can be compared with the CPU oracle), `seed`, `return_trace`."""
+    ([N,B,V] Exp(1) draws so that results can be compared with the CPU oracle), `seed`, `return_trace`, `teacher` (int [B, N]: teacher
+    forcing - step i + 1 is fed teacher[:, i], the returned ids / trace are still the model's own)."""
     if model.model_type not in ('c2i', 't2i'):
         raise Exception("please check model type")          # generate.py:144
-    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs)
+    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs, teacher=teacher)
     return (out, tr) if return_trace else out
 
 
 @torch.no_grad()
 def generate_t2v(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, return_trace=False, noise=None,
-                 cfg_iter=1.0, **sampling_kwargs):
+                 cfg_iter=1.0, teacher=None, **sampling_kwargs):
     """Continuous-latent generate (generate_video_diff.py:185-228): returns float [B, N, vae_embed_dim].
     head 'adapter2': token = vae_latent_adapter2(h) (gpt_video.py:431); head 'hidden': token = DiffLoss.sample(h, temperature,
     cfg_iter) (generate_video_diff.py:89-91,132-134) - `noise` [N, steps+1, B, C] N(0,1) draws make it reproducible.  cfg_iter != 1 is
-    DiffLoss.sample's own guidance (diffloss.py:37-41): rows [0, B/2) conditional, [B/2, B) unconditional, B even."""
+    DiffLoss.sample's own guidance (diffloss.py:37-41): rows [0, B/2) conditional, [B/2, B) unconditional, B even.  `teacher` (float
+    [B, N, C]): teacher forcing - step i + 1 is fed teacher[:, i]; the returned latents are still the model's own outputs."""
     if model.model_type != 't2v':
         raise Exception("please check model type")          # generate_video_diff.py:196
     if cfg_iter != 1.0 and model._head_code() != L.VLG_HEAD_HIDDEN:
         raise L.VlgError(-3, "cfg_iter is DiffLoss.sample's guidance: hidden head only")
-    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs, cfg_iter)
+    out, tr = _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise, return_trace, sampling_kwargs, cfg_iter, teacher=teacher)
     return (out, tr) if return_trace else out
