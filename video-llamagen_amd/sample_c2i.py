@@ -54,7 +54,8 @@ def main(args):
             return vq_model.decode_code(index_sample, qzshape)          # [-1, 1]
 
     samples = vd.sharded_call(run, [c_indices], n)
-    gpt_model.status()        # generate() is asynchronous: a device-side time-out of a persistent kernel surfaces here, before anything is written
+    if not args.serve:
+        gpt_model.status()    # generate() is asynchronous: a device-side time-out of a persistent kernel surfaces here, before anything is written
     if is_rank0():
         save_images(samples, args.out)
         print("images saved to %s.npy" % args.out)

@@ -167,6 +167,7 @@ class LLMEngine:
                         sample_logits=sp.temperature > 0, seed=seed)
         self.waves_run += 1
         rows = ids.cpu().tolist()
+        self.model.status(sync=False)      # generate() is asynchronous; the copy above waited for it: a device-side time-out surfaces here
         outs = []
         for r, row in zip(conds, rows):
             outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, row)]))
