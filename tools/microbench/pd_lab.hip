@@ -1,7 +1,7 @@
 // Lab for the persistent decode step (csrc/pdecode.hip): synthetic bf16 weights of a GPT size, M rows at position `pos`, the kernel
 // replayed `reps` times with in-kernel time stamps of layer 1 (-DVLG_PD_PROF).  Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVLG_PD_PROF -I video-llamagen_amd/csrc -I include tools/microbench/pd_lab.hip \
-//         video-llamagen_amd/csrc/core.hip -o gpurun_out/pd_lab && gpurun_out/pd_lab XL 16 600
+//         video-llamagen_amd/csrc/core.hip -o gpurun_out/pd_lab && gpurun_out/pd_lab XL 16 600 [reps] [form: 1 = pdecode.hip, 2 = pdecode2.hip]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../video-llamagen_amd/csrc/pdecode.hip"
+#include "pdecode2_lab.hip"
 
 using namespace vlg;
 
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
   const int M = argc > 2 ? atoi(argv[2]) : 16;
   const int pos = argc > 3 ? atoi(argv[3]) : 600;
   const int reps = argc > 4 ? atoi(argv[4]) : 20;
+  const int form = argc > 5 ? atoi(argv[5]) : 1;
   int D = 1280, H = 20, L = 36;
   if (!strcmp(model, "L")) D = 1024, H = 16, L = 24;
   if (!strcmp(model, "B")) D = 768, H = 12, L = 12;
@@ -84,12 +86,12 @@ int main(int argc, char** argv) {
   CK(hipHostGetDevicePointer((void**)&fault_dev, fault, 0));
   int cus = 0;
   CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-  if (!pd_ok<bf16>(M, D, H, hd, F, S, cus)) {
+  if (form == 2 ? !pd2_ok<bf16>(M, D, H, hd, F, cus) : !pd_ok<bf16>(M, D, H, hd, F, S, cus)) {
     fprintf(stderr, "shape not covered\n");
     return 1;
   }
   void* xbuf;
-  const size_t xbytes = pd_xbuf_bytes(M, D, H, hd, F, 2);
+  const size_t xbytes = form == 2 ? pd2_xbuf_bytes(M, D, H, hd, F, 2, cus) : pd_xbuf_bytes(M, D, H, hd, F, 2);
   CK(hipMalloc(&xbuf, xbytes));
   CK(hipMemset(xbuf, 0, xbytes));
   unsigned long long* prof;
@@ -100,6 +102,7 @@ int main(int argc, char** argv) {
   a.xbuf = xbuf; a.fault = fault_dev; a.spin_max = 200000;
   a.L = L; a.M = M; a.D = D; a.H = H; a.hd = hd; a.F = F; a.S = S; a.eps = 1e-5f;
   a.prof = prof;
+  a.fm = 1;   // the product streams fragment-major weights (random fill: the layout does not matter for the values here)
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());
@@ -111,7 +114,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyAsync(x, x0, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));
     set_state_k<<<1, 1, 0, st>>>(state, pos + i, 1 + i);
     CK(hipEventRecord(e0, st));
-    if (pd_layers<bf16>(a, st) != VLG_OK) {
+    if ((form == 2 ? pd2_layers<bf16>(a, st) : pd_layers<bf16>(a, st)) != VLG_OK) {
       fprintf(stderr, "launch failed: %s\n", vlg_last_error());
       return 1;
     }
@@ -125,7 +128,31 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
-  printf("%s M=%d pos=%d: %.1f us per step, %.2f us per layer\n", model, M, pos, tot / reps * 1e3, tot / reps * 1e3 / L);
+  printf("%s M=%d pos=%d form %d: %.1f us per step, %.2f us per layer\n", model, M, pos, form, tot / reps * 1e3, tot / reps * 1e3 / L);
+  if (form == 2) {
+    const Pd2Geom geo(M, D, H, hd, 2, cus);
+    printf("  geometry: row groups of %d, %d shares per (row group, head) = %d items; reducer chunks of %d columns = %d units; %d MLP slices\n", geo.rg, geo.gs,
+           geo.nitems, geo.cw, geo.nunits, F / 16);
+    std::vector<unsigned long long> p2((size_t)cus * 32);
+    CK(hipMemcpy(p2.data(), prof, p2.size() * 8, hipMemcpyDeviceToHost));
+    const char* n2[13] = {"layer start", "x swept", "qkv mfma+red", "qkv published", "q ready", "kv streamed", "shares swept", "wo partials out", "h reduced+out",
+                          "h swept", "w13 mfma+red", "w2 partials out", "x reduced+out"};
+    for (int w : {0, 1, 79, 100, 230, 250, 255}) {
+      if (w >= cus) continue;
+      const unsigned long long* t = p2.data() + (size_t)w * 32;
+      printf("wg %3d:", w);
+      unsigned long long prev = t[0];
+      for (int i = 0; i < 13; ++i) {
+        if (!t[i]) continue;
+        printf(" [%d %s +%.2f]", i, n2[i], (double)(t[i] - prev) / 100.0);
+        prev = t[i];
+      }
+      printf("  total %.2f us\n", (double)(t[12] - t[0]) / 100.0);
+      if (t[13]) printf("        fine: q ready -> K / V loop done %.2f, -> waves merged in LDS %.2f, -> partial out + barrier %.2f\n", (double)(t[13] - t[4]) / 100.0,
+                        (double)(t[14] - t[13]) / 100.0, (double)(t[5] - t[14]) / 100.0);
+    }
+    return 0;
+  }
   std::vector<unsigned long long> p((size_t)cus * 32);
   CK(hipMemcpy(p.data(), prof, p.size() * 8, hipMemcpyDeviceToHost));
   const char* names[15] = {"layer start", "x swept", "qkv mfma+red", "qkv published", "att q ready", "att streamed", "att done", "ao swept", "wo published",

@@ -1,3 +1,10 @@
+// LAB ONLY (tools/microbench/pd_lab.hip includes this file; it is not part of libvlg): the six-hand-off form of the persistent decode step,
+// built and measured in round 4 and NOT adopted - parity-green (reference goldens bit-exact in fp32, launch chain within bf16 summation
+// noise at GPT-XL width, 1...16 rows) but slower than pdecode.hip at every shape measured: GPT-XL 4 rows at position 2680 37.6 vs 34.9 us per
+// layer, 8 rows at 600 38.8 vs 31.4, 1 row 31.1 vs 28.5, GPT-L 16 rows 37.9 vs 30.8 (profiles/r04_pd_lab_stamps.txt).  Two hand-offs fewer
+// per layer saved ~6 us of waiting; the fp32 partial rows that replace them cost ~9: 224 F slices x M x D granules published (3.3 us) and
+// summed back (5.5 us) per layer, 20 heads x M x D on the attention side (3.7 us).  DESIGN.md section 5, round 4.
+//
 // Persistent decode step, second form (round 4): the L transformer layers of ONE decode step (Tq = 1, gpt.py:255-259 x n_layer) in ONE launch,
 // with SIX dependent hand-offs per layer instead of the eight of pdecode.hip.
 //
@@ -36,6 +43,64 @@
 #include "pd_common.h"
 
 namespace vlg {
+
+// ---- persistent decode step, second form (pdecode2.hip): six hand-offs per layer, small row counts ------------------------------------
+// work split of a launch, shared by host and device
+struct Pd2Geom {
+  int rg = 0, gs = 0, nitems = 0;   // attention items (row group of rg rows, head, share s of gs): n_rg * H * gs <= workgroups
+  int cw = 0, upr = 0, nunits = 0;  // reducer units (row, chunk of cw columns): M * upr <= workgroups
+  bool ok = false;
+  __host__ __device__ Pd2Geom(int M, int D, int H, int hd, int esz, int G) {
+    const int ksh = hd * esz / 64, ntd = D / 16;
+    if (ksh < 1 || G < 1) return;
+    const int tpw_max = 10 / ksh;                       // output tiles of the wo slice one wave can hold (PD2_NF fragments)
+    // row-group size: the least K / V work per item (rg rows x 1 / gs of the range); ties -> fewer rows per item
+    for (int c = 1; c <= 16; c *= 2) {
+      const int n = (M + c - 1) / c;
+      if (n * H > G) continue;
+      int g = G / (n * H);
+      if (g > 8) g = 8;
+      if (((ntd + g - 1) / g + 7) / 8 > tpw_max) continue;
+      if (rg == 0 || c * gs < rg * g) {
+        rg = c;
+        gs = g;
+      }
+    }
+    if (rg == 0) return;
+    nitems = ((M + rg - 1) / rg) * H * gs;
+    cw = ((M * D + G - 1) / G + 3) / 4 * 4;
+    if (cw < 4) cw = 4;
+    while (M * ((D + cw - 1) / cw) > G) cw += 4;
+    upr = (D + cw - 1) / cw;
+    nunits = M * upr;
+    ok = cw <= 512;
+  }
+};
+// granule offsets (8-byte units) of the exchange regions, both parities
+struct Pd2Xbuf {
+  unsigned nx, nq, nap, nwp, nw2p, per_parity;
+  __host__ __device__ Pd2Xbuf(int M, int D, int F, int H, int hd, int esz, const Pd2Geom& g) {
+    nx = (unsigned)M * D * esz / 4;
+    nq = 3 * nx;
+    nap = (unsigned)g.nitems * g.rg * (hd + 2);
+    nwp = (unsigned)M * H * D;
+    nw2p = (unsigned)(F / 16) * M * D;
+    per_parity = 2 * nx + nq + nap + nwp + nw2p;
+  }
+  __host__ __device__ unsigned X(int par) const { return par * per_parity; }            // layer input rows (T)
+  __host__ __device__ unsigned Q(int par) const { return X(par) + nx; }                 // q | k | v rows of the current position, RoPE applied (T)
+  __host__ __device__ unsigned HH(int par) const { return Q(par) + nq; }                // residual stream after attention (T)
+  __host__ __device__ unsigned AP(int par) const { return HH(par) + nx; }               // attention partials [item][row][hd + 2] (fp32)
+  __host__ __device__ unsigned WP(int par) const { return AP(par) + nap; }              // wo partial rows [m][head][D] (fp32)
+  __host__ __device__ unsigned W2P(int par) const { return WP(par) + nwp; }             // w2 partial rows [F slice][m][D] (fp32)
+  __host__ __device__ size_t bytes() const { return (size_t)2 * per_parity * 8; }
+};
+template <typename T>
+bool pd2_ok(int M, int D, int H, int hd, int F, int cus);
+size_t pd2_xbuf_bytes(int M, int D, int H, int hd, int F, int esz, int cus);
+template <typename T>
+int pd2_layers(PdArgs a, hipStream_t st);   // needs a.fm (fragment-major weight copies)
+
 
 namespace {
 
@@ -381,7 +446,16 @@ __global__ __launch_bounds__(PD2_NTHR) void pd2_layers_kernel(PdArgs a) {
   if (has_qkv) load_set(layers_c[0].wqkv, wg * 16, 0, std::integral_constant<int, 1>{});
 
   const float att_scale = 1.0f / sqrtf((float)HD);
+  const int tid_k = tid;
   for (int l = 0; l < L && alive; ++l) {
+    // Thread indices re-derived from an opaque copy once per layer: everything computed from them below (tile numbers, publish offsets,
+    // LDS addresses, predicates) is then loop-VARIANT to hipcc.  Otherwise it hoists dozens of such values out of the layer loop, runs out
+    // of registers and spills them - and each scratch reload is a vector-memory operation whose s_waitcnt vmcnt(0) also waits for every
+    // hand-off store still in flight (measured: the ten publish steps of the w2 slice serialised on it, 7 us instead of 1).
+    int tid_l = tid_k;
+    asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const unsigned lane16 = (unsigned)lane * 16u;
     struct {
       const void *wo, *w13, *w2, *norm1, *norm2;
     } ly = {layers_c[l].wo, layers_c[l].w13, layers_c[l].w2, layers_c[l].norm1, layers_c[l].norm2};
@@ -538,6 +612,7 @@ __global__ __launch_bounds__(PD2_NTHR) void pd2_layers_kernel(PdArgs a) {
           for (int j = 0; j < VEC; ++j) av[j] = fmaf(pu, DT<T>::ld(&vnew.v[j]), av[j] * alpha);
           mx = mnew;
         }
+        PD2_STAMP(13);
         // merge the lane groups of the wave, then the waves (same arithmetic as attn_partial_kernel)
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) {
@@ -559,6 +634,7 @@ __global__ __launch_bounds__(PD2_NTHR) void pd2_layers_kernel(PdArgs a) {
           }
         }
         pd_barrier();
+        PD2_STAMP(14);
         // this share's (m, l, acc[HD]) of the row: kept, and handed to the other shares
         if (tid < HD + 2) {
           float M8 = -INFINITY;
@@ -582,14 +658,19 @@ __global__ __launch_bounds__(PD2_NTHR) void pd2_layers_kernel(PdArgs a) {
       // The head's K-slice of wo for this share's output columns: requested here, behind the K / V stream (its registers are free now), and
       // landing under the exchange below.  Fragment j * KSH + k = K step it_h * KSH + k of output tile ct_lo + wave + 8 j.
       {
-        const char* wb = reinterpret_cast<const char*>(ly.wo) + ((size_t)(ct_lo + wave) * (size_t)nks_d + (size_t)it_h * KSH) * 1024;   // wave-uniform
+        // one running pointer, opaque to the optimiser: a run-time tile stride otherwise makes hipcc keep one address per fragment across the
+        // layer loop, spill them, and put a scratch reload (which queues behind the weight stream) in front of every weight request
+        const char* wp = reinterpret_cast<const char*>(ly.wo) + ((size_t)(ct_lo + wave) * (size_t)nks_d + (size_t)it_h * KSH) * 1024 + lane16;
+        size_t tstride = (size_t)PD2_NW * (size_t)nks_d * 1024;
+        asm volatile("" : "+s"(tstride));
 #pragma unroll
-        for (int j = 0; j < PD2_NF / KSH; ++j)
+        for (int j = 0; j < PD2_NF / KSH; ++j) {
           if (ct_lo + wave + PD2_NW * j < ct_hi) {
 #pragma unroll
-            for (int k = 0; k < KSH; ++k)
-              R[j * KSH + k] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(wb + lane16 + ((size_t)j * PD2_NW * nks_d + k) * 1024));
+            for (int k = 0; k < KSH; ++k) R[j * KSH + k] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(wp + k * 1024));
           }
+          wp += tstride;
+        }
       }
       // the other shares' partials
       if (GS > 1) {
@@ -689,10 +770,14 @@ __global__ __launch_bounds__(PD2_NTHR) void pd2_layers_kernel(PdArgs a) {
         constexpr int SPS = 64 / (16 * ESZ);                                      // F slices per K step (2 bf16, 1 fp32)
         const int kk = wg / SPS, half = wg % SPS;
         const bool mine = SPS == 1 || (q >> 1) == half;
-        const char* wb = reinterpret_cast<const char*>(ly.w2) + ((size_t)wave * (size_t)(F / KS) + (size_t)kk) * 1024;   // wave-uniform
+        const char* wp = reinterpret_cast<const char*>(ly.w2) + ((size_t)wave * (size_t)(F / KS) + (size_t)kk) * 1024 + lane16;
+        size_t tstride = (size_t)PD2_NW * (size_t)(F / KS) * 1024;
+        asm volatile("" : "+s"(tstride));   // running pointer, as for the wo slice
 #pragma unroll
-        for (int j = 0; j < PD2_NF; ++j)
-          if (wave + PD2_NW * j < NTD && mine) R[j] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)(wb + lane16 + (size_t)j * PD2_NW * (size_t)(F / KS) * 1024));
+        for (int j = 0; j < PD2_NF; ++j) {
+          if (wave + PD2_NW * j < NTD && mine) R[j] = __builtin_nontemporal_load((pd_gptr16)(uintptr_t)wp);
+          wp += tstride;
+        }
       }
       PD2_STAMP(10);
       pd_barrier();

@@ -69,9 +69,6 @@ struct vlg_gpt {
   int spin_max = 0;                  // option debug_spin_max (0 = default bound)
   bool pdecode = true;               // decode layers as one persistent launch per step (pdecode.hip) where the shape allows
   int pd_rows = 0;                   // ... up to this many cache rows (0 = the measured rule of pd_use())
-  bool pd2 = true;                   // ... in its six-hand-off form (pdecode2.hip) where that covers the shape and is the faster one
-  int pd2_rows = 0;                  //     up to this many cache rows (0 = the measured default)
-  long long pd2_steps = 0;           //     decode steps recorded on it (vlg_gpt_counter "pd2_steps"; also counted in pd_steps)
   bool weights_fm = true;            // stream the fragment-major weight copies (option "weights_fm"; results are bit-identical either way)
   bool act_fm = true;                // keep the fused decode chain's activations A-fragment-major (option "act_fm"; bit-identical either way)
   const int32_t* teach_ids = nullptr;   // vlg_gpt_set_teacher: forced inputs [B][N] (token heads) ...
@@ -442,15 +439,6 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->pd_rows = (int)value;
     return VLG_OK;
   }
-  if (!strcmp(key, "pd2")) {
-    h->pd2 = value != 0;
-    return VLG_OK;
-  }
-  if (!strcmp(key, "pd2_rows")) {
-    VLG_CHECK(value >= 0 && value <= 16, VLG_ERR_BAD_ARG, "pd2_rows must be in 0..16");
-    h->pd2_rows = (int)value;
-    return VLG_OK;
-  }
   if (!strcmp(key, "dl_persist")) {
     h->dl_persist_on = value != 0;
     return VLG_OK;
@@ -490,7 +478,6 @@ extern "C" int vlg_gpt_graphs_built(vlg_gpt_t* h, int64_t* count) {
 extern "C" int vlg_gpt_counter(vlg_gpt_t* h, const char* key, int64_t* count) {
   VLG_CHECK(h && key && count, VLG_ERR_BAD_ARG, "vlg_gpt_counter: null argument");
   if (!strcmp(key, "pd_steps")) *count = h->pd_steps;
-  else if (!strcmp(key, "pd2_steps")) *count = h->pd2_steps;
   else if (!strcmp(key, "chain_steps")) *count = h->chain_steps;
   else if (!strcmp(key, "graphs_built")) *count = h->graphs_built;
   else {
@@ -749,16 +736,6 @@ struct Runner {
     if (rows_cap > 0 ? Bp > rows_cap : !(Bp <= 8 || (Bp <= 16 && Bp * h->H <= cus))) return false;
     return ln->pd_xbuf.p != nullptr && h->pd_layers_dev.p != nullptr && pd_ok<T>(Bp, h->D, h->H, h->hd, h->F, S, cus);
   }
-  // the six-hand-off form (pdecode2.hip) instead of pdecode.hip: small row counts (its fp32 partial rows grow with the row count)
-  bool pd2_use() {
-    static const int off = getenv("VLG_PD2") ? (atoi(getenv("VLG_PD2")) == 0) : 0;
-    static const int rows_env = getenv("VLG_PD2_ROWS") ? atoi(getenv("VLG_PD2_ROWS")) : 0;
-    const int cap = h->pd2_rows > 0 ? h->pd2_rows : (rows_env > 0 ? rows_env : 8);
-    if (off || !h->pd2 || !h->pd_fm || Bp > cap) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return pd2_ok<T>(Bp, h->D, h->H, h->hd, h->F, cus) && ln->pd_xbuf.bytes >= pd2_xbuf_bytes(Bp, h->D, h->H, h->hd, h->F, (int)sizeof(T), cus);
-  }
   int layers_pd() {
     PdArgs a{};
     a.layers = h->pd_layers_dev.as<PdLayer>();
@@ -777,10 +754,6 @@ struct Runner {
     a.fm = h->pd_fm ? 1 : 0;
     a.L = h->L; a.M = Bp; a.D = h->D; a.H = h->H; a.hd = h->hd; a.F = h->F; a.S = S;
     a.eps = h->cfg.norm_eps;
-    if (pd2_use()) {
-      h->pd2_steps += 1;
-      return pd2_layers<T>(a, st);
-    }
     return pd_layers<T>(a, st);
   }
 
@@ -1185,14 +1158,7 @@ int reserve_lane(vlg_gpt* h, Lane& ln, int B, int Bp, int S, int pool_blocks = 0
   if (h->V > 0) VLG_TRY(ln.logits.reserve((size_t)Bp * h->V * sizeof(float)));
   VLG_TRY(ln.cur_tok.reserve((size_t)Bp * sizeof(int32_t)));
   VLG_TRY(ln.state.reserve(sizeof(StepState)));
-  if (Bp <= 32 && pool_blocks == 0) {
-    size_t xb = pd_xbuf_bytes(Bp, D, H, hd, F, (int)e);
-    int dev = 0, cus = 0;
-    if (Bp <= 16 && h->pd2 && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
-        (e == 2 ? pd2_ok<bf16>(Bp, D, H, hd, F, cus) : pd2_ok<float>(Bp, D, H, hd, F, cus)))
-      xb = std::max(xb, pd2_xbuf_bytes(Bp, D, H, hd, F, (int)e, cus));
-    VLG_TRY(ln.pd_xbuf.reserve(xb));
-  }
+  if (Bp <= 32 && pool_blocks == 0) VLG_TRY(ln.pd_xbuf.reserve(pd_xbuf_bytes(Bp, D, H, hd, F, (int)e)));
   if (!ln.st) VLG_HIP(hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking));
   if (!ln.ev) VLG_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
   return VLG_OK;
@@ -1329,7 +1295,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(int64_t)sp.cfg_interval, fbits(sp.temperature), (uint64_t)(int64_t)sp.top_k, fbits(sp.top_p),
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
-                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (h->pd2 ? 8 : 0) | (h->pd2_rows << 8) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
+                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
                                    (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset, (uint64_t)(uintptr_t)h->teach_ids, (uint64_t)(uintptr_t)h->teach_lat, (uint64_t)((h->weights_fm ? 1 : 0) | (h->act_fm ? 2 : 0))};
       {

@@ -296,63 +296,6 @@ size_t pd_xbuf_bytes(int M, int D, int H, int hd, int F, int esz);
 template <typename T>
 int pd_layers(PdArgs a, hipStream_t st);
 
-// ---- persistent decode step, second form (pdecode2.hip): six hand-offs per layer, small row counts ------------------------------------
-// work split of a launch, shared by host and device
-struct Pd2Geom {
-  int rg = 0, gs = 0, nitems = 0;   // attention items (row group of rg rows, head, share s of gs): n_rg * H * gs <= workgroups
-  int cw = 0, upr = 0, nunits = 0;  // reducer units (row, chunk of cw columns): M * upr <= workgroups
-  bool ok = false;
-  __host__ __device__ Pd2Geom(int M, int D, int H, int hd, int esz, int G) {
-    const int ksh = hd * esz / 64, ntd = D / 16;
-    if (ksh < 1 || G < 1) return;
-    const int tpw_max = 10 / ksh;                       // output tiles of the wo slice one wave can hold (PD2_NF fragments)
-    // row-group size: the least K / V work per item (rg rows x 1 / gs of the range); ties -> fewer rows per item
-    for (int c = 1; c <= 16; c *= 2) {
-      const int n = (M + c - 1) / c;
-      if (n * H > G) continue;
-      int g = G / (n * H);
-      if (g > 8) g = 8;
-      if (((ntd + g - 1) / g + 7) / 8 > tpw_max) continue;
-      if (rg == 0 || c * gs < rg * g) {
-        rg = c;
-        gs = g;
-      }
-    }
-    if (rg == 0) return;
-    nitems = ((M + rg - 1) / rg) * H * gs;
-    cw = ((M * D + G - 1) / G + 3) / 4 * 4;
-    if (cw < 4) cw = 4;
-    while (M * ((D + cw - 1) / cw) > G) cw += 4;
-    upr = (D + cw - 1) / cw;
-    nunits = M * upr;
-    ok = cw <= 512;
-  }
-};
-// granule offsets (8-byte units) of the exchange regions, both parities
-struct Pd2Xbuf {
-  unsigned nx, nq, nap, nwp, nw2p, per_parity;
-  __host__ __device__ Pd2Xbuf(int M, int D, int F, int H, int hd, int esz, const Pd2Geom& g) {
-    nx = (unsigned)M * D * esz / 4;
-    nq = 3 * nx;
-    nap = (unsigned)g.nitems * g.rg * (hd + 2);
-    nwp = (unsigned)M * H * D;
-    nw2p = (unsigned)(F / 16) * M * D;
-    per_parity = 2 * nx + nq + nap + nwp + nw2p;
-  }
-  __host__ __device__ unsigned X(int par) const { return par * per_parity; }            // layer input rows (T)
-  __host__ __device__ unsigned Q(int par) const { return X(par) + nx; }                 // q | k | v rows of the current position, RoPE applied (T)
-  __host__ __device__ unsigned HH(int par) const { return Q(par) + nq; }                // residual stream after attention (T)
-  __host__ __device__ unsigned AP(int par) const { return HH(par) + nx; }               // attention partials [item][row][hd + 2] (fp32)
-  __host__ __device__ unsigned WP(int par) const { return AP(par) + nap; }              // wo partial rows [m][head][D] (fp32)
-  __host__ __device__ unsigned W2P(int par) const { return WP(par) + nwp; }             // w2 partial rows [F slice][m][D] (fp32)
-  __host__ __device__ size_t bytes() const { return (size_t)2 * per_parity * 8; }
-};
-template <typename T>
-bool pd2_ok(int M, int D, int H, int hd, int F, int cus);
-size_t pd2_xbuf_bytes(int M, int D, int H, int hd, int F, int esz, int cus);
-template <typename T>
-int pd2_layers(PdArgs a, hipStream_t st);   // needs a.fm (fragment-major weight copies)
-
 int advance_state(StepState* state, hipStream_t st);
 int set_state(StepState* state, int pos, int step, hipStream_t st);
 // teacher forcing: cur_tok [Bp] / cur_lat [B][C] <- ids [B_total][N] / lat [B_total][N][C] at token index state->step (rows b_off..)

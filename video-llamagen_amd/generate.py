@@ -74,8 +74,6 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"weights_fm", C.c_int64(1 if getattr(model, "weights_fm", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"act_fm", C.c_int64(1 if getattr(model, "act_fm", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"pd_rows", C.c_int64(int(getattr(model, "pd_rows", 0)))))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"pd2", C.c_int64(1 if getattr(model, "pd2", True) else 0)))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"pd2_rows", C.c_int64(int(getattr(model, "pd2_rows", 0)))))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_spin_max", C.c_int64(int(getattr(model, "debug_spin_max", 0)))))
         if latent and model._head_code() == L.VLG_HEAD_HIDDEN:
             L.check(L.lib().vlg_gpt_set_option_f64(model._handle, b"cfg_iter", C.c_double(float(cfg_iter))))

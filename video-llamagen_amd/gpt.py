@@ -119,8 +119,6 @@ class Transformer:
         self.weights_fm = True   # decode GEMMs stream the fragment-major weight copies (one MFMA B fragment = 1 KB contiguous); bit-identical results
         self.act_fm = True       # the fused decode chain keeps its activations A-fragment-major; bit-identical results
         self.pd_rows = 0         # ... up to this many cache rows (0 = the library's measured default)
-        self.pd2 = True          # ... in its six-hand-off form (csrc/pdecode2.hip) at small row counts
-        self.pd2_rows = 0        #     up to this many cache rows (0 = the library's measured default)
         self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
