@@ -162,3 +162,35 @@ def test_ds16_latent_width_2048_vs_oracle(dt):
             assert _err(forced[:, 0], ref[:, 0], scale) < 8e-2 and _err(forced, ref, scale) < 4e-2, np.abs(forced - ref).max(axis=(0, 2)) / scale
         m.status()
         del m
+
+
+@pytest.mark.parametrize("rows", [64, 48])
+def test_gpt_3b_width_64_and_48_rows_vs_oracle(rows):
+    """BASELINE config 5's decode kernels: GPT-3B width (D 3200, 32 heads of 100, F 8704) on a 2-layer stack, 32 / 24 classes under guidance =
+    64 / 48 cache rows (split-K slab GEMMs on 64 x 64 tiles + reduce launches with RoPE-scatter / SwiGLU / residual + RMSNorm; head_dim 100
+    attention).  Teacher-forced with the oracle's ids, 3 steps: fp32 combined logits within 2e-3 of the range and ids equal wherever the
+    oracle's top-2 margin exceeds that; bf16 first-step logits within 8e-2 of the fp32 oracle."""
+    import video_llamagen_amd as V
+    cfg = dict(cases.GPT_SIZES["GPT-3B"], n_layer=2, vocab_size=16384, block_size=576, cls_token_num=1, model_type="c2i", num_classes=1000,
+               caption_dim=2048, norm_eps=1e-5, rope_base=10000.0, multiple_of=256, head="logits")
+    sd = _weights(cfg)
+    cls = cases.class_ids(rows // 2, 1000, seed=rows)
+    tr = {}
+    ref_ids = O.generate(O.GPTOracle(cfg, sd, "fp32"), cls, 3, None, cfg_scale=1.65, sample_logits=False, trace=tr)
+    ref_lg = np.stack(tr["logits"])
+    scale = max(1.0, float(np.abs(ref_lg).max()))
+    kw = dict(cfg_scale=1.65, sample_logits=False, return_trace=True, teacher=torch.from_numpy(ref_ids))
+    for dt, tol_ref in ((torch.float32, 2e-3), (torch.bfloat16, 8e-2)):
+        m, _ = product_gpt(cfg, dt, sd=sd)
+        ids1, t1 = V.generate(m, torch.from_numpy(cls), 3, **kw)
+        m.status()
+        lg1 = to_np(t1)
+        assert np.isfinite(lg1).all()
+        if dt == torch.float32:
+            assert _err(lg1, ref_lg, scale) < tol_ref, np.abs(lg1 - ref_lg).max(axis=(1, 2)) / scale
+            top2 = np.sort(ref_lg, axis=-1)[..., -2:]
+            decided = (top2[..., 1] - top2[..., 0]) > 2 * tol_ref * scale          # [step, b]
+            assert (ids1.cpu().numpy() == ref_ids)[decided.T].all()
+        else:
+            assert _err(lg1[0], ref_lg[0], scale) < tol_ref
+        del m

@@ -616,6 +616,8 @@ struct Runner {
     T* xn = ln->xn.as<T>();
     float* ws = ln->ws.as<float>();
     const size_t lstride = kv_lstride();
+    // (Round 4 measured the two wide matrices as one-pass 64-row GEMMs with RoPE-scatter / SwiGLU inside - tools/microbench/gemm_rows64_attempt.hip:
+    // 65.0 us per layer for wqkv + w13 against 63.1 us for the slab GEMMs + their reduce launches here, config 5 2.17 vs 2.11 s - not adopted.)
     VLG_TRY(reduce_residual_rmsnorm<T>(nullptr, 0, x, W<T>("layers.0.attention_norm.weight"), xn, M, D, h->cfg.norm_eps, st));
     for (int l = 0; l < h->L; ++l) {
       const std::string p = "layers." + std::to_string(l) + ".";
