@@ -55,3 +55,36 @@ def test_t5_real_widths_vs_oracle():
         with pytest.raises(V._lib.VlgError):
             emb.get_text_embeddings(["a cat"])                # no tokenizer in this package (sentencepiece model not shipped)
         del m
+
+
+def test_t5_embedder_from_strings_with_a_local_tokenizer_directory(tmp_path):
+    """Text -> ids -> features from STRINGS (language/t5.py:60-81): a tokenizer directory built offline with the `tokenizers` package stands in
+    for the reference's spiece.model directory (not available offline); captions are cleaned the reference's way first (caption.py), then
+    tokenised to 120 padded positions, then encoded - equal to encoding the ids by hand."""
+    import json
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    import video_llamagen_amd as V
+    words = ["<pad>", "</s>", "<unk>", "a", "cat", "dog", "photo", "of", "the", "sitting", "on", "mat", "cute"]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.save(str(tmp_path / "tokenizer.json"))
+    json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "pad_token": "<pad>", "eos_token": "</s>", "unk_token": "<unk>", "model_max_length": 120},
+              open(tmp_path / "tokenizer_config.json", "w"))
+    cfg = dict(cases.TINY_T5, vocab_size=len(words))
+    sd = detweights.t5_weights(cfg)
+    m = _model(cfg, torch.float32, sd)
+    emb = V.T5Embedder("cuda", m, tokenizer_path=str(tmp_path))
+    texts = ["A  CUTE-Cat sitting on the mat!!! https://example.com/x.png", "<b>Dog</b> photo #12"]
+    # the url rule eats "https://" and "example.com/x"; ".png" alone is no file name ([\S]+ needs a character in front), its "png" goes with the
+    # extension rule, the dot stays
+    assert [emb.text_preprocessing(t) for t in texts] == ["a cute-cat sitting on the mat!!! .", "dog photo"]
+    y, mk = emb.get_text_embeddings(texts)
+    assert tuple(y.shape) == (2, 120, cfg["d_model"]) and mk.sum(1).tolist() == [10, 2]     # "a cute - cat sitting on the mat !!! ." / "dog photo"
+    ids = emb.tokenizer([emb.text_preprocessing(t) for t in texts], max_length=120, padding="max_length", truncation=True, return_tensors="pt")
+    y2, _ = emb.get_text_embeddings_from_ids(ids["input_ids"], ids["attention_mask"])
+    assert torch.equal(y, y2)
+    ref = O.T5Oracle(cfg, sd, "fp32").encode(ids["input_ids"].numpy(), ids["attention_mask"].numpy())
+    valid = ids["attention_mask"].numpy().astype(bool)
+    assert np.abs(to_np(y) - ref)[valid].max() < 1e-3 * max(1.0, np.abs(ref[valid]).max())
+    with pytest.raises(V._lib.VlgError):
+        V.T5Embedder("cuda", m, tokenizer_path=str(tmp_path / "missing"))

@@ -122,18 +122,33 @@ class T5EncoderModel:
 
 
 class T5Embedder:
-    """language/t5.py:14-81 without the hub download: `model` is a loaded T5EncoderModel, `tokenizer` any Hugging Face style callable."""
+    """language/t5.py:14-81 without the hub download.  `model` is a loaded T5EncoderModel.  `tokenizer` is a Hugging Face style callable, or
+    `tokenizer_path` a local directory holding one (spiece.model / tokenizer.json + tokenizer_config.json, as the reference's cache directory
+    does): it is opened with transformers.AutoTokenizer - a host-side dependency the reference has too; nothing is fetched.  Captions go
+    through the reference's cleaning first (caption.py: clean_caption twice when use_text_preprocessing, else lower().strip())."""
 
-    def __init__(self, device, model, tokenizer=None, model_max_length=120):
+    def __init__(self, device, model, tokenizer=None, model_max_length=120, tokenizer_path=None, use_text_preprocessing=True):
         self.device = torch.device(device)
         self.model = model.to(self.device)
+        if tokenizer is None and tokenizer_path is not None:
+            import os
+            if not os.path.isdir(tokenizer_path):
+                raise L.VlgError(-2, "tokenizer_path %r is not a directory (no download is attempted)" % (tokenizer_path,))
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(tokenizer_path, local_files_only=True)
         self.tokenizer = tokenizer
         self.model_max_length = model_max_length
+        self.use_text_preprocessing = use_text_preprocessing
+
+    def text_preprocessing(self, text):
+        from .caption import text_preprocessing
+        return text_preprocessing(text, self.use_text_preprocessing)
 
     def get_text_embeddings(self, texts):
         if self.tokenizer is None:
-            raise L.VlgError(-6, "no tokenizer given: use get_text_embeddings_from_ids(input_ids, attention_mask)")
-        tok = self.tokenizer([t.lower().strip() for t in texts], max_length=self.model_max_length, padding="max_length", truncation=True,
+            raise L.VlgError(-6, "no tokenizer given: pass tokenizer= / tokenizer_path=, or use get_text_embeddings_from_ids(input_ids, attention_mask)")
+        texts = [self.text_preprocessing(t) for t in texts]
+        tok = self.tokenizer(texts, max_length=self.model_max_length, padding="max_length", truncation=True,
                              return_attention_mask=True, add_special_tokens=True, return_tensors="pt")
         return self.get_text_embeddings_from_ids(tok["input_ids"], tok["attention_mask"])
 
