@@ -64,8 +64,13 @@ def build_gpt(V, a, device, head=None):
     return m
 
 
-# one-GPU timings of the per-GPU shards of the 32-video job (bench.py --batch b --no-vae, + b/4 VAE decode calls of 0.11 s), DESIGN.md section 6
-PROJECTED_STRONG = {"basis_s_per_step": {"32": 18.9, "16": 12.2, "8": 8.9, "4": 6.6}, "speedup": {"2": 1.55, "4": 2.12, "8": 2.86}}
+def projected_strong():
+    """One-GPU timings of the per-GPU shards of the 32-video job and the speed-ups they project, from the tracked file tools/bench_shards.py
+    writes (measured, not typed in; the driver computes the real efficiency from its own per-N runs)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_shard_timings.json")))
+    except Exception:
+        return None
 
 
 def synth_cond(B, device, seed):
@@ -402,7 +407,7 @@ def main():
         res["gathered_shape"] = list(last.shape) if last is not None else None
         res["config"]["shard_sizes"] = [shard_range(a.batch, r, world)[1] - shard_range(a.batch, r, world)[0] for r in range(world)] \
             if scaling == "strong" else [B] * world
-        res["config"]["projected_strong_speedup_from_one_gpu_shards"] = PROJECTED_STRONG
+        res["config"]["projected_strong_speedup_from_one_gpu_shards"] = projected_strong()
 
     if rank == 0 and not a.no_roofline:
         if not roof_done:           # --warmup 0: one extra instrumented step after the timed region
@@ -443,49 +448,85 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_extras:
-        # ---- driver-observed short runs of the other configurations (bounded by the time budget) ----
+        # ---- driver-observed short runs of the other configurations (bounded by the time budget; most important first) ----
         try:
             del vae
-            torch.cuda.empty_cache()
-            extras, skipped = {}, []
-            if elapsed() + 4 <= a.budget_s and a.head != "hidden":
-                gh = build_gpt(V, a, device, head="hidden")
-                nh = a.hidden_tokens
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                V.generate_t2v(gh, cond, nh, mask)
-                torch.cuda.synchronize()
-                dth = time.perf_counter() - t
-                extras["C4_diffloss_head"] = {"workload": f"{a.gpt_model} t2v, hidden head + DiffLoss sampler (100 DDPM steps per token, gpt_video_diff.py), "
-                                                          f"{B} videos, first {nh} of 5120 latent tokens (positions 120..{119 + nh}), bf16, sampling only",
-                                              "sampling_s": dth, "tokens_per_s": B * nh / dth, "ms_per_token_step": 1e3 * dth / nh}
-                if elapsed() + 8 <= a.budget_s:
-                    # the same head at LATE context: positions 4984..5239 (the last 256 of the 5120 latent tokens) over a zero-filled cache
-                    # prefix (handle option debug_pos_offset) - what a token step costs where attention reads the whole context
-                    off = a.latent ** 2 * ((a.num_frames - 1) // 4 + 1) - nh
-                    gh.debug_pos_offset = off
-                    V.generate_t2v(gh, cond, 2, mask)            # allocation of the full-length cache outside the timed calls
-                    dtl = None
-                    for _ in range(2):                           # best of two: the first call after a 31 GB allocation has measured 40 % high once
-                        torch.cuda.synchronize()
-                        t = time.perf_counter()
-                        V.generate_t2v(gh, cond, nh, mask)
-                        torch.cuda.synchronize()
-                        d = time.perf_counter() - t
-                        dtl = d if dtl is None else min(dtl, d)
-                    extras["C4_diffloss_head_late"] = {"workload": f"as C4_diffloss_head, last {nh} of the 5120 latent tokens (positions {120 + off}..{119 + off + nh}; "
-                                                                   "earlier cache rows zero-filled)",
-                                                       "sampling_s": dtl, "tokens_per_s": B * nh / dtl, "ms_per_token_step": 1e3 * dtl / nh}
-                else:
-                    skipped.append("C4_diffloss_head_late")
-                del gh
-            else:
-                skipped.append("C4_diffloss_head")
             del gpt
             torch.cuda.empty_cache()
-            ex, sk = run_extra_configs(V, device, a.budget_s)
-            extras.update(ex)
-            skipped += sk
+            extras, skipped = run_extra_configs(V, device, a.budget_s)
+
+            def timed_t2v(g, n):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                V.generate_t2v(g, cond, n, mask)
+                torch.cuda.synchronize()
+                g.status(sync=False)
+                return time.perf_counter() - t
+
+            # the secondary shape of config 4 (gpt_video.py:381-401,704-714): spatial downsample 16 -> 2048-wide latent tokens,
+            # 5 x 16 x 16 = 1280 of them (S 1400); the latent adapters run as generic GEMMs (C > 16)
+            if elapsed() + 9 <= a.budget_s and a.head != "hidden":
+                a16 = argparse.Namespace(**vars(a))
+                a16.latent, a16.vae_embed_dim = 16, 2048
+                g16 = build_gpt(V, a16, device)
+                n16 = vae_t * 16 * 16
+                V.generate_t2v(g16, cond, 2, mask)
+                d16 = timed_t2v(g16, n16)
+                extras["C4_ds16"] = {"workload": f"{a.gpt_model} t2v (adapter2 head), 120 text tokens + {n16} latent tokens ({vae_t}x16x16, vae_embed_dim 2048), "
+                                                 f"{B} videos, bf16, sampling only", "sampling_s": d16, "tokens_per_s": B * n16 / d16}
+                del g16
+                torch.cuda.empty_cache()
+            else:
+                skipped.append("C4_ds16")
+            # the DiffLoss head (gpt_video_diff.py: 100 DDPM steps per token) in three 256-token windows of the 5120-token sequence - start,
+            # middle, end (option debug_pos_offset: decode starts `offset` positions in, over a zero-filled cache prefix) - and the full-length
+            # time they interpolate to (trapezoid over the windows' mid positions; the token step grows linearly with the context it attends to)
+            if elapsed() + 5 <= a.budget_s and a.head != "hidden":
+                gh = build_gpt(V, a, device, head="hidden")
+                nh = a.hidden_tokens
+                ntot = a.latent ** 2 * vae_t
+                win = {}
+                dth = timed_t2v(gh, nh)
+                win[0] = dth
+                extras["C4_diffloss_head"] = {"workload": f"{a.gpt_model} t2v, hidden head + DiffLoss sampler (100 DDPM steps per token, gpt_video_diff.py), "
+                                                          f"{B} videos, first {nh} of {ntot} latent tokens (positions 120..{119 + nh}), bf16, sampling only",
+                                              "sampling_s": dth, "tokens_per_s": B * nh / dth, "ms_per_token_step": 1e3 * dth / nh}
+                for tag, off in (("late", ntot - nh), ("mid", (ntot - nh) // 2)):
+                    if elapsed() + 8 > a.budget_s:
+                        skipped.append("C4_diffloss_head_" + tag)
+                        continue
+                    gh.debug_pos_offset = off
+                    V.generate_t2v(gh, cond, 2, mask)            # allocation of the full-length cache outside the timed calls
+                    dtl = min(timed_t2v(gh, nh) for _ in range(2))   # best of two: the first call after a 31 GB allocation has measured 40 % high once
+                    win[off] = dtl
+                    extras["C4_diffloss_head_" + tag] = {"workload": f"as C4_diffloss_head, {nh} tokens from position {120 + off} (earlier cache rows zero-filled)",
+                                                         "sampling_s": dtl, "tokens_per_s": B * nh / dtl, "ms_per_token_step": 1e3 * dtl / nh}
+                if len(win) >= 2:
+                    pts = sorted((off + nh / 2.0, d / nh) for off, d in win.items())   # (window mid position, seconds per token step)
+                    full = pts[0][1] * pts[0][0] + pts[-1][1] * (ntot - pts[-1][0])      # flat extension to both ends
+                    for (p0, t0_), (p1, t1_) in zip(pts, pts[1:]):
+                        full += 0.5 * (t0_ + t1_) * (p1 - p0)
+                    extras["C4_diffloss_head_full_length_interpolated"] = {
+                        "workload": f"{ntot}-token generate of {B} videos with the DiffLoss head, interpolated from the {len(win)} measured windows",
+                        "sampling_s": full, "tokens_per_s": B * ntot / full, "windows_ms_per_token_step": {str(int(p)): 1e3 * t for p, t in pts}}
+                gh.debug_pos_offset = 0
+                del gh
+                torch.cuda.empty_cache()
+                # the reference's only shipped t2v launch line runs fp32 (scripts/sample/sample_t2v_diff.bash:26, --precision none)
+                if elapsed() + 9 <= a.budget_s:
+                    a32 = argparse.Namespace(**vars(a))
+                    a32.dtype = "fp32"
+                    g32 = build_gpt(V, a32, device, head="hidden")
+                    V.generate_t2v(g32, cond, 2, mask)
+                    d32 = timed_t2v(g32, nh)
+                    extras["C4_diffloss_head_fp32"] = {"workload": f"as C4_diffloss_head in fp32 (--precision none), first {nh} tokens", "sampling_s": d32,
+                                                       "tokens_per_s": B * nh / d32, "ms_per_token_step": 1e3 * d32 / nh}
+                    del g32
+                else:
+                    skipped.append("C4_diffloss_head_fp32")
+            else:
+                skipped.append("C4_diffloss_head")
+            torch.cuda.empty_cache()
             res["extra_configs"] = extras
             res["extra_configs_skipped"] = skipped
         except Exception as e:
