@@ -35,4 +35,5 @@ def test_bench_two_ranks_strong_scaling_ragged():
     assert d["gathered_shape"] == [6, 48, 8]                 # 2 ranks x the largest shard (3) x 48 tokens x vae_embed_dim 8
     assert d["value"] > 0 and abs(d["value"] - 5 * 48 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["tokens_per_s_per_gpu"] == pytest.approx(d["value"] / 2)
-    assert "speedup" in d["config"]["projected_strong_speedup_from_one_gpu_shards"]
+    proj = d["config"]["projected_strong_speedup_from_one_gpu_shards"]      # measured shard timings from the tracked file, or None without it
+    assert proj is None or ("speedup_vs_one_gpu" in proj and "s_per_step" in proj)
