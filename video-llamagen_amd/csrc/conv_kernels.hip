@@ -316,6 +316,19 @@ extern "C" int vlg_conv_lab_count(unsigned* n) { return hipMemcpyFromSymbol(n, H
 // loads, LDS-DMA and weight LDS stores.  The stamps and ablations of tools/conv_lab.py: a step's memory instructions cost 0.45 us on
 // top of 0.96 us of fragment reads + MFMAs when they sit in the same instruction streams (each vector-memory instruction holds its
 // wave at the issue stage for 100+ cycles, MFMAs of that wave behind it); in waves of their own they run beside the MFMAs.
+// Chunk swizzle of a 64-byte LDS row (patch rows and weight rows): the 16-byte chunk c of row r sits at position c ^ ht_swz<T>(r).
+//   fp32 (32x32x2 MFMAs, lane = (row of 32, K half)): (r >> 2) & 3, conflict-free for the 32-row fragment reads at every tap offset.
+//   bf16 (round 4: 16x16x32 MFMAs, lane = (row of 16, chunk 0..3)): ((r >> 2) & 1) << 1 - searched over all 4-entry tables of (r >> 2) & 3 and
+//   all 64 alignments of the first row against ds_read_b128's lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: this one is
+//   conflict-free everywhere, (r >> 2) & 3 is 2-way on most alignments for that lane shape.
+template <typename T>
+__device__ __forceinline__ int ht_swz(int r) {
+  if constexpr (sizeof(T) == 2)
+    return ((r >> 2) & 1) << 1;
+  else
+    return (r >> 2) & 3;
+}
+
 template <typename T, int HT_TT, int HT_TH, bool WS>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
 __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
                                                                const float* __restrict__ bias, const T* __restrict__ residual,
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   const int wrow = (ltid & 511) >> 2, wch = ltid & 3;
   const uint4* wbase = reinterpret_cast<const uint4*>(w) + ((size_t)(n0 + wrow) * taps * d.Cin) / EPV + wch;
   const size_t wrow2 = ((size_t)64 * taps * d.Cin) / EPV;   // 64 weight rows further
-  const int wslot = wrow * 4 + (wch ^ ((wrow >> 2) & 3));   // rows r and r + 64 share (r >> 2) & 3: the second slot is wslot + 256
+  const int wslot = wrow * 4 + (wch ^ ht_swz<T>(wrow));   // rows r and r + 64 share the swizzle: the second slot is wslot + 256
   const int cin8 = d.Cin / EPV;   // 16-byte chunks per (cout, tap) weight row
   const int rows_per_chunk = d.kt * 3;          // steps per channel chunk
   const int Q = ncc * rows_per_chunk;
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
 #pragma unroll
   for (int k = 0; k < HT_SLOTS; ++k) {
     const int e = ltid + NL * k;
-    const int hr = e >> 2, ch = (e & 3) ^ ((hr >> 2) & 3);
+    const int hr = e >> 2, ch = (e & 3) ^ ht_swz<T>(hr);
     hoff[k] = -2;
     if (is_loader && hr < nrows) {
       const int f = hr / (HT_HH * HT_HW), rem = hr - f * (HT_HH * HT_HW);
@@ -507,59 +520,83 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
     }
   }
 
-  // fragment roles
-  int hb[NWM];
+  // fragment roles.  bf16: 16x16x32 MFMAs - four 16-position blocks x four 16-channel blocks per wave, lane = (row r16 of the block, 16-byte
+  // chunk q of the 64-byte row): one ds_read_b128 per block and tap feeds four MFMAs of K = 32, the same LDS bytes and the same MFMA cycles
+  // as the 32x32x16 form (2 K halves x 2 x 2 blocks) it replaces - but the chip holds a higher clock on this shape under load
+  // (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15 x the FLOP/s at equal cycles).  fp32: 32x32x2 as before.
+  constexpr bool B16 = sizeof(T) == 2;
+  constexpr int NMB = B16 ? 2 * NWM : NWM, NNB = B16 ? 4 : 2;   // position blocks / channel blocks per wave
+  constexpr int ACCN = B16 ? 4 : 16;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  int hb[NMB];
 #pragma unroll
-  for (int mi = 0; mi < NWM; ++mi) {
-    const int m = wave_m * (32 * NWM) + mi * 32 + r32;
+  for (int mi = 0; mi < NMB; ++mi) {
+    const int m = B16 ? wave_m * (32 * NWM) + mi * 16 + r16 : wave_m * (32 * NWM) + mi * 32 + r32;
     hb[mi] = ((m >> TSH) * HT_HH + ((m >> 5) & (HT_TH - 1))) * HT_HW + (m & 31);
   }
-  f32x16_t acc[NWM][2];
+  typedef float accv_t __attribute__((ext_vector_type(ACCN)));
+  accv_t acc[NMB][NNB];
 #pragma unroll
-  for (int mi = 0; mi < NWM; ++mi)
+  for (int mi = 0; mi < NMB; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NNB; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      for (int e = 0; e < ACCN; ++e) acc[mi][ni][e] = 0.f;
 
   auto compute = [&](const uint4* hbuf, const uint4* wbuf, int toff) __attribute__((always_inline)) {   // toff: patch row offset of tap (a, i, 0)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+      if constexpr (B16) {
+        uint4 af[NMB], bfr[NNB];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 af[NWM], bfr[2];
-#pragma unroll
-        for (int mi = 0; mi < NWM; ++mi) {
+        for (int mi = 0; mi < NMB; ++mi) {
           const int row = hb[mi] + toff + j;
-          af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
+          af[mi] = hbuf[row * 4 + (q4 ^ ht_swz<T>(row))];
         }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int row = wave_n * 64 + ni * 32 + r32;
-          bfr[ni] = wbuf[j * 512 + row * 4 + ((2 * kk + hh) ^ ((row >> 2) & 3))];
+        for (int ni = 0; ni < NNB; ++ni) {
+          const int row = wave_n * 64 + ni * 16 + r16;
+          bfr[ni] = wbuf[j * 512 + row * 4 + (q4 ^ ht_swz<T>(row))];
         }
-        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int mi = 0; mi < NWM; ++mi)
+        for (int mi = 0; mi < NMB; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]),
-                                                                    acc[mi][ni], 0, 0, 0);
-        } else {
+          for (int ni = 0; ni < NNB; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mi]), __builtin_bit_cast(bf16x8_t, bfr[ni]),
+                                                                  acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          uint4 af[NMB], bfr[NNB];
+#pragma unroll
+          for (int mi = 0; mi < NMB; ++mi) {
+            const int row = hb[mi] + toff + j;
+            af[mi] = hbuf[row * 4 + ((2 * kk + hh) ^ ht_swz<T>(row))];
+          }
+#pragma unroll
+          for (int ni = 0; ni < NNB; ++ni) {
+            const int row = wave_n * 64 + ni * 32 + r32;
+            bfr[ni] = wbuf[j * 512 + row * 4 + ((2 * kk + hh) ^ ht_swz<T>(row))];
+          }
           // K = 2 per MFMA: element e of the hh = 0 lanes' chunk pairs with element e of the hh = 1 lanes' chunk - any pairing of
           // the 16 channels works as long as both operands use the same one
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mi = 0; mi < NWM; ++mi)
+            for (int mi = 0; mi < NMB; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
+              for (int ni = 0; ni < NNB; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&af[mi].x)[e]), __uint_as_float((&bfr[ni].x)[e]),
                                                                    acc[mi][ni], 0, 0, 0);
         }
       }
     }
   };
+  // accumulator element e of block (mi, ni) of this lane -> (position m of the tile, channel c of the 128)
+  auto acc_pos = [&](int mi, int e) __attribute__((always_inline)) {
+    return B16 ? wave_m * (32 * NWM) + mi * 16 + 4 * q4 + e : wave_m * (32 * NWM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+  };
+  auto acc_ch = [&](int ni) __attribute__((always_inline)) { return B16 ? wave_n * 64 + ni * 16 + r16 : wave_n * 64 + ni * 32 + r32; };
 
   // prologue: patch of chunk 0, weights of steps 0 and 1
   LAB_STAMP(5);
@@ -632,16 +669,13 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
     };
     load_batch(0);   // in flight while the accumulators go to LDS
 #pragma unroll
-    for (int mi = 0; mi < NWM; ++mi)
+    for (int mi = 0; mi < NMB; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int c = wave_n * 64 + ni * 32 + r32;
+      for (int ni = 0; ni < NNB; ++ni) {
+        const int c = acc_ch(ni);
         const float bv = bias ? bias[n0 + c] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = wave_m * (32 * NWM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          Ls[m * LP + c] = acc[mi][ni][e] + bv;
-        }
+        for (int e = 0; e < ACCN; ++e) Ls[acc_pos(mi, e) * LP + c] = acc[mi][ni][e] + bv;
       }
     __syncthreads();
 #pragma unroll
@@ -667,25 +701,25 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   }
   const long long pper = (long long)d.To * d.Ho * d.Wo;
 #pragma unroll
-  for (int mi = 0; mi < NWM; ++mi) {
+  for (int mi = 0; mi < NMB; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int co = n0 + wave_n * 64 + ni * 32 + r32;
+    for (int ni = 0; ni < NNB; ++ni) {
+      const int co = n0 + acc_ch(ni);
       const float bv = bias ? bias[co] : 0.f;
-      long long pe[16];
-      float rv[16];
+      long long pe[ACCN];
+      float rv[ACCN];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = wave_m * (32 * NWM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      for (int e = 0; e < ACCN; ++e) {
+        const int m = acc_pos(mi, e);
         const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
         pe[e] = (t < d.To && y < d.Ho && x < d.Wo) ? (((long long)b * d.To + t) * d.Ho + y) * d.Wo + x : -1;
       }
-      if (residual) {   // all 16 residual values requested before the first use
+      if (residual) {   // all residual values requested before the first use
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = DT<T>::ld(residual + (pe[e] >= 0 ? pe[e] : 0) * d.Cout + co);
+        for (int e = 0; e < ACCN; ++e) rv[e] = DT<T>::ld(residual + (pe[e] >= 0 ? pe[e] : 0) * d.Cout + co);
       }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < ACCN; ++e) {
         if (pe[e] < 0) continue;
         float v = acc[mi][ni][e] + bv;
         if (residual) v += rv[e];
