@@ -733,6 +733,127 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
   LAB_STAMP(8);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow-output halo convolution (round 4): the 3x3 (x kt) stride-1 causal convs with at most 4 output channels - conv_out of both
+// decoders (128 -> 3, on the LARGEST activation of a decode: [4, 17, 256, 256, 128] bf16 = 1.14 GB).  On conv_mfma_kernel<32> that layer
+// re-fetched every input element once per tap through L2 -> LDS (27 x 1.14 GB) for 3 useful columns of a 32-wide MFMA tile: 3.5 ms of a
+// 94 ms decode call.  Here: the halo tile of conv_halo_kernel (256 output positions, the (2 + kt - 1) x 6 x 34 input patch of a
+// 32-channel chunk staged in LDS once and walked by the taps), 16x16x32 MFMAs whose B operand holds the <= 4 weight rows in lanes
+// r16 < NCO and zeros elsewhere, 4 waves x 4 position blocks, single-buffered (66 KB of LDS: two workgroups per compute unit overlap
+// each other's gather and compute phases).  bf16 only; planar fp32 or channels-last output; no residual.
+// ---------------------------------------------------------------------------------------------------------------
+template <int HT_TT, int HT_TH, int NCO>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(ConvDesc d, const bf16* __restrict__ in, const bf16* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out_cl, float* __restrict__ out_planar) {
+  typedef bf16 T;
+  constexpr int EPV = 8, KC = 32;
+  static_assert(HT_TT * HT_TH * HT_TW == 256, "256 positions per tile");
+  constexpr int HT_HH = HT_TH + 2;
+  constexpr int TSH = (HT_TH == 4) ? 7 : 8;
+  extern __shared__ __attribute__((aligned(16))) uint4 nt_smem[];
+  uint4* hbuf = nt_smem;                        // patch [816 rows][4 chunks], swizzled
+  uint4* wbuf = nt_smem + HT_MAXROWS * 4;       // weights of the chunk [taps][NCO][4 chunks]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int taps = d.kt * 9, ncc = d.Cin / KC;
+  const int nTw = (d.Wo + HT_TW - 1) / HT_TW, nTh = (d.Ho + HT_TH - 1) / HT_TH, nTt = (d.To + HT_TT - 1) / HT_TT;
+  int bid = blockIdx.x;
+  const int x0 = (bid % nTw) * HT_TW;
+  bid /= nTw;
+  const int y0 = (bid % nTh) * HT_TH;
+  bid /= nTh;
+  const int t0 = (bid % nTt) * HT_TT;
+  const int b = bid / nTt;
+  const int HF = HT_TT + d.kt - 1;
+  const int nrows = HF * HT_HH * HT_HW;
+  const int He = d.Hi << d.up, We = d.Wi << d.up;
+  const uint4* in16 = reinterpret_cast<const uint4*>(in);
+  // gather roles: LDS slot e = tid + 256 k holds patch row e >> 2, source chunk (e & 3) ^ swizzle(row)
+  constexpr int NS = (HT_MAXROWS * 4 + 255) / 256;   // 13
+  long long hoff[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int e = tid + 256 * k;
+    const int hr = e >> 2, ch = (e & 3) ^ ht_swz<T>(hr);
+    hoff[k] = -2;
+    if (hr < nrows) {
+      const int f = hr / (HT_HH * HT_HW), rem = hr - f * (HT_HH * HT_HW);
+      const int y = rem / HT_HW, x = rem - y * HT_HW;
+      int ti = t0 + f - (d.kt - 1);
+      ti = ti < 0 ? 0 : ti;                       // causal: frame 0 replicated in front (conv.py:126-129)
+      ti = ti > d.Ti - 1 ? d.Ti - 1 : ti;
+      const int uy = y0 + y - 1, ux = x0 + x - 1;
+      hoff[k] = -1;
+      if (uy >= 0 && ux >= 0 && uy < He && ux < We)
+        hoff[k] = (((((long long)b * d.Ti + ti) * d.Hi + (uy >> d.up)) * d.Wi + (ux >> d.up)) * d.Cin) / EPV + ch;
+    }
+  }
+  int hb[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = wave * 64 + mi * 16 + r16;
+    hb[mi] = ((m >> TSH) * HT_HH + ((m >> 5) & (HT_TH - 1))) * HT_HW + (m & 31);
+  }
+  typedef float f32x4n_t __attribute__((ext_vector_type(4)));
+  f32x4n_t acc[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4n_t{0.f, 0.f, 0.f, 0.f};
+  const int nwch = taps * NCO * 4;   // weight chunks of one channel chunk
+  for (int cc = 0; cc < ncc; ++cc) {
+    uint4 pv[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) pv[k] = hoff[k] >= 0 ? in16[hoff[k] + cc * 4] : make_uint4(0, 0, 0, 0);
+    uint4 wv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;          // (tap, co, chunk)
+      const int ch = e & 3, co = (e >> 2) % NCO, tap = e / (4 * NCO);
+      wv[k] = (e < nwch && co < d.Cout) ? reinterpret_cast<const uint4*>(w)[((size_t)(co * taps + tap) * d.Cin + cc * KC) / EPV + ch] : make_uint4(0, 0, 0, 0);
+    }
+    if (cc > 0) __syncthreads();            // the previous chunk's fragments have been read
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (hoff[k] != -2) hbuf[tid + 256 * k] = pv[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 256 * k < nwch) wbuf[tid + 256 * k] = wv[k];
+    __syncthreads();
+    for (int tap = 0; tap < taps; ++tap) {
+      const int a = tap / 9, ij = tap - a * 9;
+      const int toff = (a * HT_HH + ij / 3) * HT_HW + ij % 3;
+      const uint4 bfr = r16 < NCO ? wbuf[(tap * NCO + r16) * 4 + q4] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = hb[mi] + toff;
+        const uint4 af = hbuf[row * 4 + (q4 ^ ht_swz<T>(row))];
+        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bfr), acc[mi], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane (channel r16, q4) holds positions 4 q4 .. 4 q4 + 3 of each 16-position block = four consecutive x
+  if (r16 >= d.Cout) return;
+  const float bv = bias ? bias[r16] : 0.f;
+  const long long pper = (long long)d.To * d.Ho * d.Wo;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = wave * 64 + mi * 16 + 4 * q4;
+    const int t = t0 + (m >> TSH), y = y0 + ((m >> 5) & (HT_TH - 1)), x = x0 + (m & 31);
+    if (t >= d.To || y >= d.Ho) continue;
+    const long long p = (((long long)b * d.To + t) * d.Ho + y) * d.Wo + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (x + e >= d.Wo) break;
+      const float v = acc[mi][e] + bv;
+      if (out_cl)
+        DT<T>::st(out_cl + (p + e) * d.Cout + r16, v);
+      else
+        out_planar[((long long)b * d.Cout + r16) * pper + (p + e - (long long)b * pper)] = v;
+    }
+  }
+}
+constexpr int NARROW_NCO = 4;
+constexpr size_t NARROW_LDS_BYTES = (size_t)(HT_MAXROWS * 4 + 27 * NARROW_NCO * 4) * sizeof(uint4);
+
 static bool conv_halo_ok(const ConvDesc& d, int kc) {
   return d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 && d.ph0 < 0 && d.pw0 < 0 && d.Cin % kc == 0 &&
          d.Cout % 128 == 0 && d.To == d.Ti && d.Ho == (d.Hi << d.up) && d.Wo == (d.Wi << d.up);
@@ -863,6 +984,25 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
         else
           conv_halo_kernel<T, 2, 4, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
       }
+      return VLG_OK;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // narrow outputs (conv_out: Cout 3) on the halo tile instead of the im2col kernel: conv_narrow_kernel
+    static const bool narrow_off = getenv("VLG_CONV_NARROW") != nullptr && atoi(getenv("VLG_CONV_NARROW")) == 0;   // A/B knob
+    if (!narrow_off && residual == nullptr && d.Cout <= NARROW_NCO && d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 &&
+        d.ph0 < 0 && d.pw0 < 0 && d.Cin % 32 == 0 && d.To == d.Ti && d.Ho == (d.Hi << d.up) && d.Wo == (d.Wi << d.up)) {
+      static LdsAttrOnce narrow_once;
+      VLG_TRY(set_max_dynamic_lds(narrow_once, {reinterpret_cast<const void*>(conv_narrow_kernel<2, 4, NARROW_NCO>), reinterpret_cast<const void*>(conv_narrow_kernel<1, 8, NARROW_NCO>)},
+                                  (int)NARROW_LDS_BYTES));
+      const bf16* in_b = reinterpret_cast<const bf16*>(in);
+      const bf16* w_b = reinterpret_cast<const bf16*>(w);
+      bf16* out_b = reinterpret_cast<bf16*>(out_cl);
+      if (d.To == 1 && d.kt == 1)
+        conv_narrow_kernel<1, 8, NARROW_NCO><<<(unsigned)((long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW)), 256, NARROW_LDS_BYTES, st>>>(d, in_b, w_b, bias, out_b, out_planar);
+      else
+        conv_narrow_kernel<2, 4, NARROW_NCO><<<(unsigned)((long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW)), 256, NARROW_LDS_BYTES, st>>>(d, in_b, w_b, bias, out_b, out_planar);
+      VLG_HIP(hipGetLastError());
       return VLG_OK;
     }
   }
