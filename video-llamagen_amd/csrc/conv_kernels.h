@@ -17,9 +17,13 @@ struct ConvDesc {
 
 // out = conv(in) + bias (+ residual).  w: [Cout][taps][Cin] (re-laid out at load time), bias fp32 [Cout].
 // out_cl (channels-last, dtype T) or out_planar (fp32 [B, Cout, To, Ho, Wo], the API output layout); one must be null.
+// gn_part (optional): the GroupNorm (32 groups) statistics of the OUTPUT are accumulated in the epilogue (halo-tile path, channels-last output)
+// as per-tile partial sums [B][*gn_nblk][32][{sum, sumsq}] doubles, fixed order, no atomics; *gn_nblk = 0 when the launch that ran cannot
+// provide them (the caller then lets group_norm() make its own statistics pass).  Buffer: conv_gn_part_doubles(d) doubles.
 template <typename T>
 int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl,
-                 float* out_planar, hipStream_t st);
+                 float* out_planar, hipStream_t st, double* gn_part = nullptr, int* gn_nblk = nullptr);
+size_t conv_gn_part_doubles(const ConvDesc& d);
 
 // HIP-event bracket around every halo-tile (MFMA) conv launch on its own stream; read() waits for the events and returns the sums
 int conv_timing_enable(bool on);
@@ -31,7 +35,7 @@ constexpr int kGnPosPerBlock = 512;
 size_t group_norm_scratch_bytes(int B, long long P);
 template <typename T>
 int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
-               bool swish, hipStream_t st);
+               bool swish, hipStream_t st, const double* given_part = nullptr, int given_nblk = 0);
 
 // single-head spatial self-attention per frame (vq_model.py:335-347, attention.py:60-70): q,k,v,out [NF][HW][C], scale C^-0.5
 template <typename T>

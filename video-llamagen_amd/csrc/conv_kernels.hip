@@ -332,7 +332,7 @@ __device__ __forceinline__ int ht_swz(int r) {
 template <typename T, int HT_TT, int HT_TH, bool WS>   // output tile: HT_TT frames x HT_TH rows x 32 columns = 256 positions (2 x 4 video, 1 x 8 images)
 __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, const T* __restrict__ in, const T* __restrict__ w,
                                                                const float* __restrict__ bias, const T* __restrict__ residual,
-                                                               T* __restrict__ out_cl, float* __restrict__ out_planar) {
+                                                               T* __restrict__ out_cl, float* __restrict__ out_planar, double* __restrict__ gn_part) {
   constexpr int NWM = 2;
   constexpr int NTHR = 1024 / NWM;           // 512 MFMA threads
   constexpr int NL = WS ? 256 : NTHR;        // threads that load
@@ -515,7 +515,14 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
         if (q + 1 < Q) VLG_LOADER_STEP(q + 1, wrB, wrA);
       }
 #undef VLG_LOADER_STEP
-      if (out_cl != nullptr) __syncthreads();   // the epilogue's barrier
+      if (out_cl != nullptr) {
+        __syncthreads();   // the epilogue's barrier
+        if (gn_part != nullptr) {   // ... and the three of its statistics reduction
+          __syncthreads();
+          __syncthreads();
+          __syncthreads();
+        }
+      }
       return;
     }
   }
@@ -678,6 +685,11 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
         for (int e = 0; e < ACCN; ++e) Ls[acc_pos(mi, e) * LP + c] = acc[mi][ni][e] + bv;
       }
     __syncthreads();
+    // GroupNorm statistics of the tensor being written (round 4): a thread's items all lie in the same CH channels (i % IPR does
+    // not depend on k), so it keeps CH running sums / sums of squares of the ROUNDED values it stores; reduced per group below in a fixed order
+    float gs[CH], gq[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
     for (int k0 = 0; k0 < NIT; k0 += NB) {
       if (k0 > 0) load_batch(k0);
@@ -693,7 +705,50 @@ __global__ __launch_bounds__(WS ? 768 : 512) void conv_halo_kernel(ConvDesc d, c
         const T* re = reinterpret_cast<const T*>(&rv[k]);
 #pragma unroll
         for (int j = 0; j < CH; ++j) DT<T>::st(oe + j, residual ? vv[j] + DT<T>::ld(re + j) : vv[j]);
-        if (off[k] >= 0) *reinterpret_cast<uint4*>(out_cl + off[k]) = ov;
+        if (off[k] >= 0) {
+          *reinterpret_cast<uint4*>(out_cl + off[k]) = ov;
+          if (gn_part != nullptr) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              const float o = DT<T>::ld(oe + j);
+              gs[j] += o;
+              gq[j] += o * o;
+            }
+          }
+        }
+      }
+    }
+    if (gn_part != nullptr) {
+      // per-thread partials -> LDS (the tile image is dead) -> stage 1: thread (comp, channel) adds the NTHR / IPR threads that share its
+      // channel chunk, in thread order (independent LDS loads: a serial chain of dependent ones here cost 3 us per workgroup) -> stage 2:
+      // thread (group, comp) adds its group's channels.  Doubles from stage 1 on; part[b][tile][group][{sum, sumsq}] as gn_finalize_kernel reads it
+      __syncthreads();
+      float* Ps = reinterpret_cast<float*>(ht_smem);
+      constexpr int PST = CH + 1;   // row stride: the 8 chunks a wave reads in stage 1 fall on different banks
+      static_assert((size_t)(2 * NTHR * PST) * sizeof(float) + 256 * sizeof(double) <= HT_LDS_BYTES, "statistics partials fit the main loop's LDS");
+      double* Qs = reinterpret_cast<double*>(Ps + 2 * NTHR * PST);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        Ps[(0 * NTHR + tid) * PST + j] = gs[j];
+        Ps[(1 * NTHR + tid) * PST + j] = gq[j];
+      }
+      __syncthreads();
+      if (tid < 256) {
+        const int comp = tid >> 7, ch = tid & 127, chunk = ch / CH, j = ch - chunk * CH;
+        double tot = 0.0;
+#pragma unroll 8
+        for (int t2 = chunk; t2 < NTHR; t2 += IPR) tot += (double)Ps[(comp * NTHR + t2) * PST + j];
+        Qs[tid] = tot;
+      }
+      __syncthreads();
+      const int cg = d.Cout / 32, ngr = 128 / cg;   // channels per group, groups inside this 128-channel tile
+      if (tid < 2 * ngr) {
+        const int g = tid >> 1, comp = tid & 1;
+        double tot = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) tot += Qs[comp * 128 + c];
+        const int tiles_b = nTt * nTh * nTw;
+        const int tile = (int)blockIdx.x - b * tiles_b;
+        gn_part[(((size_t)b * tiles_b + tile) * 32 + n0 / cg + g) * 2 + comp] = tot;
       }
     }
     LAB_STAMP(8);
@@ -858,6 +913,10 @@ static bool conv_halo_ok(const ConvDesc& d, int kc) {
   return d.kh == 3 && d.kw == 3 && (d.kt == 1 || d.kt == 3) && d.sh == 1 && d.tmode == 0 && d.ph0 < 0 && d.pw0 < 0 && d.Cin % kc == 0 &&
          d.Cout % 128 == 0 && d.To == d.Ti && d.Ho == (d.Hi << d.up) && d.Wo == (d.Wi << d.up);
 }
+size_t conv_gn_part_doubles(const ConvDesc& d) {   // the larger of the two tilings (images: 8 x 32, video: 2 x 4 x 32)
+  const size_t tv = (size_t)cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW), ti = (size_t)cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW) * (size_t)d.To;
+  return (size_t)d.B * std::max(tv, ti) * 64;
+}
 
 // direct convolution for layers the MFMA kernel does not tile (Cin % 32 != 0: z_channels / codebook_embed_dim inputs)
 // and for the fp32 handle dtype (parity tests at toy sizes).  One thread per (position, cout).
@@ -941,7 +1000,8 @@ int conv_timing_read(double* ms_sum, double* flop_sum, long long* launches) {
 
 template <typename T>
 int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, const T* residual, T* out_cl, float* out_planar,
-                 hipStream_t st) {
+                 hipStream_t st, double* gn_part, int* gn_nblk) {
+  if (gn_nblk) *gn_nblk = 0;
   if ((out_cl == nullptr) == (out_planar == nullptr)) {
     set_error("conv_forward: exactly one output must be given");
     return VLG_ERR_BAD_ARG;
@@ -971,18 +1031,21 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
       // leave the issue slots the loads need).  VLG_CONV_WS=0 / 1: A/B knob for both dtypes
       static const int ws_knob = getenv("VLG_CONV_WS") ? atoi(getenv("VLG_CONV_WS")) : -1;
       const bool ws = ws_knob < 0 ? sizeof(T) == 2 : ws_knob != 0;
+      if (out_cl == nullptr || d.Cout % 32 != 0 || 128 % (d.Cout / 32) != 0) gn_part = nullptr;   // statistics ride on the channels-last epilogue only
       if (d.To == 1 && d.kt == 1) {   // images: the whole 256-position tile in one frame (patch 10 x 34 <= HT_MAXROWS)
+        if (gn_part && gn_nblk) *gn_nblk = cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW);
         const dim3 grid((unsigned)((long long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, HT_TW)), (unsigned)(d.Cout / 128));
         if (ws)
-          conv_halo_kernel<T, 1, 8, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+          conv_halo_kernel<T, 1, 8, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar, gn_part);
         else
-          conv_halo_kernel<T, 1, 8, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+          conv_halo_kernel<T, 1, 8, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar, gn_part);
       } else {
+        if (gn_part && gn_nblk) *gn_nblk = cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW);
         const dim3 grid((unsigned)((long long)d.B * cdiv(d.To, 2) * cdiv(d.Ho, 4) * cdiv(d.Wo, HT_TW)), (unsigned)(d.Cout / 128));
         if (ws)
-          conv_halo_kernel<T, 2, 4, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+          conv_halo_kernel<T, 2, 4, true><<<grid, 768, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar, gn_part);
         else
-          conv_halo_kernel<T, 2, 4, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar);
+          conv_halo_kernel<T, 2, 4, false><<<grid, 512, HT_LDS_BYTES, st>>>(d, in, w, bias, residual, out_cl, out_planar, gn_part);
       }
       return VLG_OK;
     }
@@ -1029,8 +1092,8 @@ int conv_forward(const ConvDesc& d, const T* in, const T* w, const float* bias, 
   conv_naive_kernel<T><<<dim3((unsigned)cdiv64(total, 256)), 256, 0, st>>>(d, in, w, bias, residual, out_cl, out_planar);
   return VLG_OK;
 }
-template int conv_forward<float>(const ConvDesc&, const float*, const float*, const float*, const float*, float*, float*, hipStream_t);
-template int conv_forward<bf16>(const ConvDesc&, const bf16*, const bf16*, const float*, const bf16*, bf16*, float*, hipStream_t);
+template int conv_forward<float>(const ConvDesc&, const float*, const float*, const float*, const float*, float*, float*, hipStream_t, double*, int*);
+template int conv_forward<bf16>(const ConvDesc&, const bf16*, const bf16*, const float*, const bf16*, bf16*, float*, hipStream_t, double*, int*);
 
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups) + optional swish, channels-last
@@ -1160,7 +1223,7 @@ size_t group_norm_scratch_bytes(int B, long long P) { return (size_t)B * 64 * si
 
 template <typename T>
 int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* stats, int B, long long P, int C, float eps,
-               bool swish, hipStream_t st) {
+               bool swish, hipStream_t st, const double* given_part, int given_nblk) {
   if (C % 32 != 0) {
     set_error("group_norm: C=%d not divisible by 32 groups", C);
     return VLG_ERR_BAD_SHAPE;
@@ -1172,13 +1235,15 @@ int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* 
                                            // [B][nblk][64] per-block partials
   float2* mr = reinterpret_cast<float2*>(stats);
   const double cnt = (double)P * (C / 32);
+  // given_part: the producing convolution already left per-tile partials [B][given_nblk][32][2] (conv_halo_kernel's epilogue): no statistics pass
+  const bool have = given_part != nullptr && given_nblk > 0;
   if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
-    gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
-    gn_finalize_kernel<<<B, 1024, 0, st>>>(part, mr, nblk, cnt, (double)eps);
+    if (!have) gn_stats_kernel<T, 8><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
+    gn_finalize_kernel<<<B, 1024, 0, st>>>(have ? given_part : part, mr, have ? given_nblk : nblk, cnt, (double)eps);
     gn_apply_kernel<T, 8><<<g1, 256, 0, st>>>(x, y, gamma, beta, mr, P, C, swish ? 1 : 0, ppb);
   } else if (C <= 256 && 256 % C == 0) {
-    gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
-    gn_finalize_kernel<<<B, 1024, 0, st>>>(part, mr, nblk, cnt, (double)eps);
+    if (!have) gn_stats_kernel<T, 1><<<g1, 256, 0, st>>>(x, part, P, C, ppb);
+    gn_finalize_kernel<<<B, 1024, 0, st>>>(have ? given_part : part, mr, have ? given_nblk : nblk, cnt, (double)eps);
     gn_apply_kernel<T, 1><<<g1, 256, 0, st>>>(x, y, gamma, beta, mr, P, C, swish ? 1 : 0, ppb);
   } else {
     set_error("group_norm: unsupported channel count %d", C);
@@ -1186,8 +1251,8 @@ int group_norm(const T* x, T* y, const float* gamma, const float* beta, double* 
   }
   return VLG_OK;
 }
-template int group_norm<float>(const float*, float*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t);
-template int group_norm<bf16>(const bf16*, bf16*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t);
+template int group_norm<float>(const float*, float*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t, const double*, int);
+template int group_norm<bf16>(const bf16*, bf16*, const float*, const float*, double*, int, long long, int, float, bool, hipStream_t, const double*, int);
 
 // ---------------------------------------------------------------------------------------------------------------
 // spatial single-head attention: one wave per query row, online softmax over the frame's HW keys

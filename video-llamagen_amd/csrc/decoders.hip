@@ -23,6 +23,13 @@ struct Act {
   void* p = nullptr;
   int slot = -1;
   int B = 0, T = 1, H = 0, W = 0, C = 0;
+  double* gn_part = nullptr;   // GroupNorm statistics partials left by the convolution that produced this tensor (conv_forward gn_part), or null
+  int gn_nblk = 0, gn_slot = -1;
+  void disown() {   // a copy taken for its shape: it owns neither the buffer nor the statistics of the original
+    slot = gn_slot = -1;
+    gn_part = nullptr;
+    gn_nblk = 0;
+  }
   long long P() const { return (long long)T * H * W; }
   long long numel() const { return (long long)B * P() * C; }
 };
@@ -116,8 +123,11 @@ struct Store {
   }
   void put(Act& a) {
     if (a.slot >= 0) busy[a.slot] = false;
-    a.slot = -1;
+    if (a.gn_slot >= 0) busy[a.gn_slot] = false;
+    a.slot = a.gn_slot = -1;
     a.p = nullptr;
+    a.gn_part = nullptr;
+    a.gn_nblk = 0;
   }
   void release_all() {
     for (size_t i = 0; i < busy.size(); ++i) busy[i] = false;
@@ -151,8 +161,26 @@ struct Net {
     y.B = d.B; y.T = d.To; y.H = d.Ho; y.W = d.Wo; y.C = d.Cout;
     if (residual) VLG_CHECK(residual->numel() == y.numel(), VLG_ERR_BAD_SHAPE, "%s: residual shape mismatch", name.c_str());
     if (!planar_out) VLG_TRY(s.get((size_t)y.numel() * sizeof(T), y));
-    return conv_forward<T>(d, (const T*)x.p, w->buf.as<T>(), b ? b->buf.as<float>() : nullptr, residual ? (const T*)residual->p : nullptr,
-                           planar_out ? nullptr : (T*)y.p, planar_out, st);
+    // every 3x3 output of a decoder is followed by a GroupNorm (norm2, the next block's norm1, norm_out): let the convolution's epilogue
+    // accumulate its statistics (no separate read pass over the tensor); tensors from other producers keep the statistics kernel
+    y.gn_part = nullptr;
+    y.gn_nblk = 0;
+    y.gn_slot = -1;
+    static const bool gnf_off = getenv("VLG_GN_FUSE") != nullptr && atoi(getenv("VLG_GN_FUSE")) == 0;   // A/B knob
+    if (!gnf_off && !planar_out && d.kh == 3 && d.Cout % 128 == 0 && stride == 1) {
+      Act tmp;
+      VLG_TRY(s.get(conv_gn_part_doubles(d) * sizeof(double), tmp));
+      y.gn_part = reinterpret_cast<double*>(tmp.p);
+      y.gn_slot = tmp.slot;
+    }
+    VLG_TRY(conv_forward<T>(d, (const T*)x.p, w->buf.as<T>(), b ? b->buf.as<float>() : nullptr, residual ? (const T*)residual->p : nullptr,
+                            planar_out ? nullptr : (T*)y.p, planar_out, st, y.gn_part, &y.gn_nblk));
+    if (y.gn_part && y.gn_nblk == 0) {   // the launch that ran could not provide them
+      s.busy[y.gn_slot] = false;
+      y.gn_part = nullptr;
+      y.gn_slot = -1;
+    }
+    return VLG_OK;
   }
 
   int gn(const Act& x, const std::string& name, bool swish, Act& y) {
@@ -161,11 +189,11 @@ struct Net {
     VLG_CHECK(g && b, VLG_ERR_STATE, "GroupNorm %s was never loaded", name.c_str());
     VLG_CHECK(g->shape[0] == x.C, VLG_ERR_BAD_SHAPE, "%s: %lld channels vs activation %d", name.c_str(), (long long)g->shape[0], x.C);
     y = x;
-    y.slot = -1;
+    y.disown();
     VLG_TRY(s.get((size_t)x.numel() * sizeof(T), y));
     VLG_TRY(s.stats.reserve(group_norm_scratch_bytes(x.B, x.P())));
     return group_norm<T>((const T*)x.p, (T*)y.p, g->buf.as<float>(), b->buf.as<float>(), s.stats.as<double>(), x.B, x.P(), x.C, 1e-6f,
-                         swish, st);
+                         swish, st, x.gn_part, x.gn_nblk);
   }
 
   // ResnetBlock (vq_model.py:299-314) / ResnetBlock3D (resnet_block.py:158-172); consumes x
@@ -183,6 +211,7 @@ struct Net {
     } else {
       xs = x;
       x.slot = -1;
+      x.gn_slot = -1;   // (the statistics buffer went with it)
     }
     VLG_TRY(conv(h3, p + ".conv2", 0, &xs, out));
     s.put(h3);
@@ -202,7 +231,7 @@ struct Net {
     if (q12 && x.T > 1) {
       for (Act* a : {&q, &k, &v}) {
         Act tmp = *a;
-        tmp.slot = -1;
+        tmp.disown();
         VLG_TRY(s.get((size_t)a->numel() * sizeof(T), tmp));
         VLG_TRY(q12_permute<T>((const T*)a->p, (T*)tmp.p, x.B, x.T, HW, x.C, false, st));
         s.put(*a);
@@ -210,7 +239,7 @@ struct Net {
       }
     }
     o = q;
-    o.slot = -1;
+    o.disown();
     VLG_TRY(s.get((size_t)q.numel() * sizeof(T), o));
     VLG_TRY(spatial_attention<T>((const T*)q.p, (const T*)k.p, (const T*)v.p, (T*)o.p, x.B * x.T, HW, x.C, st));
     s.put(q);
@@ -218,7 +247,7 @@ struct Net {
     s.put(v);
     if (q12 && x.T > 1) {
       Act tmp = o;
-      tmp.slot = -1;
+      tmp.disown();
       VLG_TRY(s.get((size_t)o.numel() * sizeof(T), tmp));
       VLG_TRY(q12_permute<T>((const T*)o.p, (T*)tmp.p, x.B, x.T, HW, x.C, true, st));
       s.put(o);
@@ -298,14 +327,14 @@ static int vq_decode_impl(vlg_vq* h, const int32_t* codes, int B, int gh, int gw
         VLG_TRY(net.attn(b, p + ".attn." + std::to_string(j), false, a));
       } else {
         a = b;
-        b.slot = -1;
+        b.disown();
       }
     }
     if (li != nres - 1) {
       VLG_TRY(net.conv(a, "decoder.conv_blocks." + std::to_string(li) + ".upsample.conv", 1, nullptr, b));  // nearest 2x + conv (:375-377)
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
   }
   VLG_TRY(net.gn(a, "decoder.norm_out", true, b));            // :191-192
@@ -400,29 +429,29 @@ static int vae_decode_impl(vlg_vae* h, const float* z, int B, int t, int hh, int
   VLG_TRY(net.attn(b, "decoder.mid.attn_1", true, a));
   VLG_TRY(net.resblock(a, "decoder.mid.block_2", b));
   a = b;
-  b.slot = -1;
+  b.disown();
   for (int lvl = h->cfg.n_mult - 1; lvl >= 0; --lvl) {         // :249-257
     const std::string p = "decoder.up." + std::to_string(lvl);
     for (int j = 0; j <= h->cfg.num_res_blocks; ++j) {
       VLG_TRY(net.resblock(a, p + ".block." + std::to_string(j), b));
       a = b;
-      b.slot = -1;
+      b.disown();
     }
     if (h->cfg.spatial_upsample[lvl]) {
       VLG_TRY(net.conv(a, p + ".upsample.conv", 1, nullptr, b)); // SpatialUpsample2x: nearest 2x + (1,3,3) causal conv
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
     if (h->cfg.temporal_upsample[lvl] && a.T > 1) {
       b = a;
-      b.slot = -1;
+      b.disown();
       b.T = 2 * a.T - 1;
       VLG_TRY(s.get((size_t)b.numel() * sizeof(T), b));
       VLG_TRY(time_upsample2x<T>((const T*)a.p, (T*)b.p, a.B, a.T, (long long)a.H * a.W * a.C, st));
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
   }
   VLG_TRY(net.gn(a, "decoder.norm_out", true, b));
@@ -460,7 +489,7 @@ static int vq_encode_impl(vlg_vq* h, const float* x_planar, int B, int Hh, int W
   VLG_TRY(net.conv(a, "encoder.conv_in", 0, nullptr, b));   // vq_model.py:106
   s.put(a);
   a = b;
-  b.slot = -1;
+  b.disown();
   for (int li = 0; li < nres; ++li) {                       // :108-114
     const std::string p = "encoder.conv_blocks." + std::to_string(li);
     for (int j = 0; j < h->cfg.num_res_blocks; ++j) {
@@ -469,14 +498,14 @@ static int vq_encode_impl(vlg_vq* h, const float* x_planar, int B, int Hh, int W
         VLG_TRY(net.attn(b, p + ".attn." + std::to_string(j), false, a));
       } else {
         a = b;
-        b.slot = -1;
+        b.disown();
       }
     }
     if (li != nres - 1) {
       VLG_TRY(net.conv_down2(a, p + ".downsample.conv", b));
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
   }
   VLG_TRY(net.resblock(a, "encoder.mid.0", b));
@@ -521,30 +550,30 @@ static int vae_encode_impl(vlg_vae* h, const float* x_planar, int B, int Tn, int
   VLG_TRY(net.conv(a, "encoder.conv_in", 0, nullptr, b));     // modeling_causalvae.py:128
   s.put(a);
   a = b;
-  b.slot = -1;
+  b.disown();
   for (int lvl = 0; lvl < h->cfg.n_mult; ++lvl) {            // :129-140
     const std::string p = "encoder.down." + std::to_string(lvl);
     for (int j = 0; j < h->cfg.num_res_blocks; ++j) {
       VLG_TRY(net.resblock(a, p + ".block." + std::to_string(j), b));
       a = b;
-      b.slot = -1;
+      b.disown();
     }
     if (s.has(p + ".downsample.conv.conv.weight")) {         // SpatialDownsample2x
       VLG_CHECK(a.H % 2 == 0 && a.W % 2 == 0, VLG_ERR_BAD_SHAPE, "odd spatial size at encoder level %d", lvl);
       VLG_TRY(net.conv_down2(a, p + ".downsample.conv", b));
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
     if (lvl < 8 && h->enc_time_down[lvl] && a.T > 1) {       // TimeDownsample2x
       b = a;
-      b.slot = -1;
+      b.disown();
       b.T = (a.T - 1) / 2 + 1;
       VLG_TRY(s.get((size_t)b.numel() * sizeof(T), b));
       VLG_TRY(time_downsample2x<T>((const T*)a.p, (T*)b.p, a.B, a.T, (long long)a.H * a.W * a.C, st));
       s.put(a);
       a = b;
-      b.slot = -1;
+      b.disown();
     }
   }
   VLG_TRY(net.resblock(a, "encoder.mid.block_1", b));
@@ -628,7 +657,7 @@ static int vqvae_decode_impl(vlg_vqvae* h, const int32_t* codes, int B, int t, i
     VLG_CHECK(g && b && rm && rv, VLG_ERR_STATE, "BatchNorm %s was never loaded", p.c_str());
     VLG_CHECK(g->shape[0] == in.C, VLG_ERR_BAD_SHAPE, "%s: channel mismatch", p.c_str());
     o = in;
-    o.slot = -1;
+    o.disown();
     VLG_TRY(s.get((size_t)in.numel() * sizeof(T), o));
     return bn_relu<T>((const T*)in.p, (T*)o.p, g->buf.as<float>(), b->buf.as<float>(), rm->buf.as<float>(), rv->buf.as<float>(),
                       (long long)in.B * in.P(), in.C, true, st);
@@ -657,7 +686,7 @@ static int vqvae_decode_impl(vlg_vqvae* h, const int32_t* codes, int B, int t, i
       VLG_TRY(lin.conv(c, q + "w_ks", 0, nullptr, kk));
       VLG_TRY(lin.conv(c, q + "w_vs", 0, nullptr, vv));
       oo = qq;
-      oo.slot = -1;
+      oo.disown();
       VLG_TRY(s.get((size_t)qq.numel() * sizeof(T), oo));
       VLG_TRY(axial_attention<T>((const T*)qq.p, (const T*)kk.p, (const T*)vv.p, (T*)oo.p, c.B, c.T, c.H, c.W, nhd, dk, axes[k], st));
       s.put(qq);
@@ -668,7 +697,7 @@ static int vqvae_decode_impl(vlg_vqvae* h, const int32_t* codes, int B, int t, i
     }
     s.put(c);
     Act nx = x;
-    nx.slot = -1;
+    nx.disown();
     VLG_TRY(s.get((size_t)x.numel() * sizeof(T), nx));
     VLG_TRY(add4<T>((const T*)x.p, (const T*)outs[0].p, (const T*)outs[1].p, (const T*)outs[2].p, (T*)nx.p, x.numel(), st));
     for (auto& o : outs) s.put(o);
