@@ -85,13 +85,13 @@ def synth_cond(B, device, seed):
 
 def cpu_baseline(a):
     """The numpy oracle (a port, not the reference) on the host cores, on a bounded sample of the same workload: GPT-XL t2v fp32,
-    same shapes, batch 4, prefill + 120 decode steps; then one latent frame (16 x 16 cells) of the CausalVideoVAE decoder at full width; then BASELINE
+    same shapes, batch 4, prefill + 240 decode steps; then one latent frame (16 x 16 cells) of the CausalVideoVAE decoder at full width; then BASELINE
     config 1 exactly (about 20-25 s in all)."""
     import threadpoolctl  # noqa: F401  (numpy BLAS thread count is reported)
     threadpoolctl.threadpool_limits(limits=16)   # a one-GPU box's share of the host (more BLAS threads than that oversubscribe it: 2x slower)
     from oracle import cases, detweights
     from oracle import vlg_oracle as O
-    cb, nsteps = 4, 121    # ~15-20 s on 16 host threads since the oracle stopped copying weights per call and attending over unwritten cache rows
+    cb, nsteps = 4, 241    # ~15-20 s on 16 host threads since the oracle stopped copying weights per call and attending over unwritten cache rows
     cfg = dict(cases.GPT_SIZES[a.gpt_model], vocab_size=16384, block_size=a.latent ** 2, cls_token_num=120, model_type="t2v",
                num_classes=1000, caption_dim=2048, norm_eps=1e-5, rope_base=10000.0, multiple_of=256,
                vae_embed_dim=a.vae_embed_dim, num_frames=a.num_frames, t_downsample_size=4, head="adapter2",

@@ -70,6 +70,18 @@ __device__ __forceinline__ float block_sum_256(float s, float* red) {
   return t;
 }
 
+template <int TPB>   // `red`: TPB / 64 floats of LDS; the wave sums are added in wave order
+__device__ __forceinline__ float block_sum_n(float s, float* red) {
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < TPB / 64; ++i) t += red[i];
+  __syncthreads();
+  return t;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k = 0.7978845608028654f;
@@ -498,19 +510,21 @@ int reduce_store(const float* ws, int splits, T* out, float* out_f32, int M, int
 template int reduce_store<float>(const float*, int, float*, float*, int, int, int, hipStream_t, const float*);
 template int reduce_store<bf16>(const float*, int, bf16*, float*, int, int, int, hipStream_t, const bf16*);
 
-// NV = 4-element vectors per thread (row = 256 threads x NV x 4 elements): one workgroup per row, the whole row in
-// registers, every split-K slab requested up front (compile-time bound, predicated) with 16-byte loads.
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ ws, int splits,
+// NV = 4-element vectors per thread (row = TPB threads x NV x 4 elements): one workgroup per row, the whole row in
+// registers, every split-K slab requested up front (compile-time bound, predicated) with 16-byte loads.  TPB = 1024 with one vector per
+// thread for the few-row launches of the decode slab path (config 5: 64 workgroups on 256 compute units, each a chain of dependent loads -
+// four times the loads in flight per row; round 4).
+template <typename T, int NV, int TPB = 256>
+__global__ __launch_bounds__(TPB) void reduce_residual_rmsnorm_kernel(const float* __restrict__ ws, int splits,
                                                                       T* __restrict__ h, const T* __restrict__ w,
                                                                       T* __restrict__ hn, int M, int D, float eps) {
-  __shared__ float red[4];
+  __shared__ float red[TPB / 64];
   const int m = blockIdx.x;
   T* hr = h + (size_t)m * D;
   float v[NV][4], g[NV][4];
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
-    const int i = (e * 256 + threadIdx.x) * 4;
+    const int i = (e * TPB + threadIdx.x) * 4;
     if (i < D) {
       const Pack<T, 4> pv = *reinterpret_cast<const Pack<T, 4>*>(hr + i);
       const Pack<T, 4> pg = *reinterpret_cast<const Pack<T, 4>*>(w + i);
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const floa
       const float* row = ws + ((size_t)(k < splits ? k : 0) * M + m) * D;
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
-        const int i = (e * 256 + threadIdx.x) * 4;
+        const int i = (e * TPB + threadIdx.x) * 4;
         part[k][e] = (k < splits && i < D) ? *reinterpret_cast<const float4*>(row + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const floa
         s[2] += part[k][e].z;
         s[3] += part[k][e].w;
       }
-      const int i = (e * 256 + threadIdx.x) * 4;
+      const int i = (e * TPB + threadIdx.x) * 4;
       if (i < D) {
         Pack<T, 4> po;
 #pragma unroll
@@ -562,11 +576,11 @@ __global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const floa
   for (int e = 0; e < NV; ++e)
 #pragma unroll
     for (int j = 0; j < 4; ++j) ss += v[e][j] * v[e][j];
-  ss = block_sum_256(ss, red);
+  ss = block_sum_n<TPB>(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)D + eps);
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
-    const int i = (e * 256 + threadIdx.x) * 4;
+    const int i = (e * TPB + threadIdx.x) * 4;
     if (i < D) {
       Pack<T, 4> po;
 #pragma unroll
@@ -582,7 +596,10 @@ int reduce_residual_rmsnorm(const float* ws, int splits, T* h, const T* w, T* hn
     set_error("rmsnorm: dim %d / splits %d not supported (dim %% 4 == 0, dim <= 4096)", D, splits);
     return VLG_ERR_UNSUPPORTED;
   }
-  if (D <= 1024)
+  static const bool wide_off = getenv("VLG_NORM_WIDE") != nullptr && atoi(getenv("VLG_NORM_WIDE")) == 0;   // A/B knob
+  if (!wide_off && D > 1024 && M <= 256)
+    reduce_residual_rmsnorm_kernel<T, 1, 1024><<<M, 1024, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
+  else if (D <= 1024)
     reduce_residual_rmsnorm_kernel<T, 1><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
   else if (D <= 2048)
     reduce_residual_rmsnorm_kernel<T, 2><<<M, 256, 0, st>>>(ws, splits, h, w, hn, M, D, eps);
