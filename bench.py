@@ -523,8 +523,31 @@ def main():
                     extras["C4_diffloss_head_fp32"] = {"workload": f"as C4_diffloss_head in fp32 (--precision none), first {nh} tokens", "sampling_s": d32,
                                                        "tokens_per_s": B * nh / d32, "ms_per_token_step": 1e3 * d32 / nh}
                     del g32
+                    torch.cuda.empty_cache()
                 else:
                     skipped.append("C4_diffloss_head_fp32")
+                # DiffLoss.sample's own guidance (cfg_iter != 1, diffloss.py:37-41,240-248; generate_video_diff.py:81-133 passes it through): the B videos
+                # as 2B network rows - (conditional, unconditional) pairs (b, b + B) - i.e. 64 rows: the persistent sampler on groups of eight rows
+                if elapsed() + 8 <= a.budget_s and 2 * B <= 64:
+                    gg = build_gpt(V, a, device, head="hidden")
+                    cond2, mask2 = torch.cat([cond, torch.zeros_like(cond)]), torch.cat([mask, mask])
+
+                    def timed_guided(n):
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        V.generate_t2v(gg, cond2, n, mask2, cfg_iter=2.0)
+                        torch.cuda.synchronize()
+                        gg.status(sync=False)
+                        return time.perf_counter() - t
+
+                    timed_guided(2)
+                    dg = timed_guided(nh)
+                    extras["C4_diffloss_head_guided"] = {"workload": f"as C4_diffloss_head with DiffLoss.sample's guidance (cfg_iter 2.0): {B} videos = {2 * B} network rows "
+                                                                     f"(pairs b, b + {B}), first {nh} tokens, bf16", "sampling_s": dg, "tokens_per_s": B * nh / dg,
+                                                         "ms_per_token_step": 1e3 * dg / nh}
+                    del gg
+                else:
+                    skipped.append("C4_diffloss_head_guided")
             else:
                 skipped.append("C4_diffloss_head")
             torch.cuda.empty_cache()

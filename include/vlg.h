@@ -140,7 +140,7 @@ int vlg_gpt_last_algorithmic_bytes(vlg_gpt_t* h, double* weight_bytes, double* k
  * with HIP events (on the stream the kernels run on) around layer 0's split-KV attention kernel of every step.
  * Kernel-selection switches, results unchanged up to fp32 summation order: "fuse_gemm" (1: fused decode
  * GEMMs and fused DiffLoss / latent heads), "fuse_swiglu" (1), "dl_persist" (1: DiffLoss sampler as one persistent launch per
- * token), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts; "pd_rows" = row
+ * token - workgroup groups of 4 rows up to 32 rows at width 1024, of 8 rows up to 64; 4 / 8: that group height, the per-step launch chain when it does not fit; 0: the chain), "pdecode" (1: all transformer layers of a decode step as one persistent launch where the shape allows, small row counts; "pd_rows" = row
  * cap replacing the measured rule), "weights_fm" (1) / "act_fm" (1): the decode GEMMs read fragment-major copies of
  * the Linear weights (one MFMA B fragment = 1 KB contiguous, built at the first call after a load; twice the weight memory for those
  * tensors) and the fused chain keeps its activations A-fragment-major - whole-cache-line requests, bit-identical results; "debug_pos_offset" (0; benchmarks: decode starts `offset` positions after the condition, over zeroed

@@ -547,6 +547,108 @@ def test_diffloss_persistent_sampler_bench_instance_vs_oracle(dt):
     assert np.abs(chain - ref).max() < tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,guided", [(6, False), (11, False), (13, False), (2, True), (6, True), (10, True)])
+def test_diffloss_persistent_sampler_eight_row_groups(B, guided):
+    """Round 4: groups of EIGHT rows (dl_persist_kernel<..., R = 8>: the form the launcher picks when groups of four would need more
+    workgroups than the chip has compute units - 33..64 rows at W 1024, i.e. 32 samples under DiffLoss.sample's own guidance), forced here
+    on small shapes with option dl_persist = 8.  Against the oracle (pinned by the reference's DiffLoss.sample goldens), against the
+    four-row form (same per-row arithmetic in the same order: bit-identical) and the launch chain; ragged last groups (11 = 8 + 3,
+    13 = 8 + 5 rows; 6 / 10 guided rows = 3 / 5 pairs against 4 pairs per group); depth 3 (resident phases) and depth 2 (streamed)."""
+    import video_llamagen_amd as V
+    for depth in (3, 2):
+        m, cfg, sd = _diff_model_w(torch.float32, 256, 10, depth=depth)
+        C, N, S = cfg["vae_embed_dim"], 3, 10
+        noise = cases.rng(73).standard_normal((N, S + 1, B, C), dtype=np.float32)
+        c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4, 3, 6, 8, 2, 7, 5, 1][:B])
+        kw = dict(temperature=0.9, noise=torch.from_numpy(noise))
+        if guided:
+            kw["cfg_iter"] = 1.8
+        om = O.GPTOracle(cfg, sd, "fp32")
+        ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=0.9,
+                                  **({"cfg_iter": 1.8} if guided else {}))
+        out = {}
+        for mode in (8, 4, False):
+            m.dl_persist = mode
+            out[mode] = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), **kw))
+            assert np.isfinite(out[mode]).all(), (mode, depth)
+            assert np.abs(out[mode] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), (mode, depth)
+        assert np.array_equal(out[8], out[4]), depth
+        assert np.abs(out[8] - out[False]).max() < 2e-4 * max(1.0, np.abs(ref).max())
+        m.dl_persist = 8
+        a = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5, **({"cfg_iter": 1.8} if guided else {}))   # Philox draws
+        m.dl_persist = 4
+        b = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), seed=5, **({"cfg_iter": 1.8} if guided else {}))
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("width,depth", [(512, 3), (768, 3), (512, 4), (1024, 3)])
+def test_diffloss_persistent_sampler_eight_row_groups_kernel_variants(width, depth):
+    """The other instantiations at eight rows per group, fp32 and bf16: one K block per wave with every phase resident (W 512), guarded K
+    blocks (W 768), runtime depth (4), fp32 at W 1024 (four K blocks per wave, depth 3 only) - oracle in fp32, the four-row form bit for bit
+    in both dtypes."""
+    import video_llamagen_amd as V
+    m, cfg, sd = _diff_model_w(torch.float32, width, 10, depth)
+    C, N, S, B = cfg["vae_embed_dim"], 2, 10, 11
+    noise = cases.rng(75).standard_normal((N, S + 1, B, C), dtype=np.float32)
+    c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5, 7, 1, 4, 3, 6, 8, 2, 7])
+    om = O.GPTOracle(cfg, sd, "fp32")
+    ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S), c, N, mk, noise, temperature=1.0)
+    out = {}
+    for mode in (8, 4):
+        m.dl_persist = mode
+        out[mode] = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise)))
+        assert np.abs(out[mode] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), mode
+    # the same arithmetic per row; the two instantiations are separate compilations, and hipcc's fused-multiply-add selection may differ
+    # between them (seen at runtime depth: last-bit differences) - 1e-6 of the range there, bit-identical at the reference's depth
+    if depth == 3:
+        assert np.array_equal(out[8], out[4])
+    else:
+        assert np.abs(out[8] - out[4]).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    mb, _, _ = _diff_model_w(torch.bfloat16, width, 10, depth)
+    ob = {}
+    for mode in (8, 4):
+        mb.dl_persist = mode
+        ob[mode] = V.generate_t2v(mb, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise))
+    assert torch.isfinite(ob[8]).all()
+    if depth == 3:
+        assert torch.equal(ob[8], ob[4])
+    else:
+        assert (ob[8][:, 0] - ob[4][:, 0]).abs().max().item() < 8e-2 * max(1.0, ob[4][:, 0].abs().max().item())
+
+
+def test_diffloss_persistent_sampler_64_rows_full_width():
+    """What the eight-row groups are for: 64 rows at W 1024, depth 3, bf16, 100 reverse steps - 8 groups x 32 column tiles = 256 workgroups,
+    chosen by the launcher on its own (groups of four would need 512).  32 samples under DiffLoss.sample's guidance (64 network rows) and 64
+    plain rows: the bf16 ORACLE on the first token (8e-2 of the range, the bar of the other full-width bf16 tests), the launch chain, and
+    bitwise repeatability."""
+    import video_llamagen_amd as V
+    m, cfg, sd = _diff_model_w(torch.bfloat16, 1024, 100)
+    C, S = cfg["vae_embed_dim"], 100
+    for B, guided in ((64, True), (64, False), (40, False)):
+        N = 1
+        noise = cases.rng(77).standard_normal((N, S + 1, B, C), dtype=np.float32)
+        c, mk = cases.text_cond(B, cfg["cls_token_num"], cfg["caption_dim"], lens=[1 + (3 * i) % 8 for i in range(B)])
+        extra = {"cfg_iter": 2.0} if guided else {}
+        m.dl_persist = True
+        a = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise), **extra)
+        b = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise), **extra)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+        om = O.GPTOracle(cfg, sd, "bf16")
+        ref = O.generate_t2v_diff(om, O.DiffLossOracle(sd, num_sampling_steps=S, dt="bf16"), c, N, mk, noise, temperature=1.0, **extra)
+        sc = max(1.0, np.abs(ref).max())
+        assert np.abs(to_np(a) - ref).max() < 8e-2 * sc, (B, guided, np.abs(to_np(a) - ref).max())
+        m.dl_persist = False
+        ch = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise), **extra)
+        assert np.abs(to_np(ch) - ref).max() < 8e-2 * sc
+        if B == 64 and not guided:   # the launcher really took the persistent kernel: forcing groups of four at 64 rows is refused ...
+            m.dl_persist = 4
+            c4 = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise))
+            assert torch.equal(c4, ch)                     # ... i.e. falls to the launch chain
+            m.dl_persist = 8
+            c8 = V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), noise=torch.from_numpy(noise))
+            assert torch.equal(c8, a)
+
+
 def test_persistent_kernel_timeout_is_an_error_not_nan():
     """A wait inside a persistent kernel that runs out must surface as VLG_ERR_STATE (vlg_gpt_status / the mirror's generate), not as
     NaN results under VLG_OK.  Injected cheaply: debug_spin_max = 1 makes the first in-launch wait that is not satisfied at once give

@@ -1,7 +1,7 @@
 // Timing lab for the persistent DiffLoss sampler (csrc/diffloss_persist.hip) on synthetic weights: whole-launch time and in-kernel
 // time stamps of one reverse step (workgroup 0).  Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVLG_DP_PROF -I video-llamagen_amd/csrc -I include tools/microbench/dl_persist_lab.hip \
-//         video-llamagen_amd/csrc/core.hip -o tools/microbench/bin/dl_persist_lab && tools/microbench/bin/dl_persist_lab [B] [W] [S]
+//         video-llamagen_amd/csrc/core.hip -o tools/microbench/bin/dl_persist_lab && tools/microbench/bin/dl_persist_lab [B] [W] [S] [rows per group]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -40,7 +40,7 @@ static bf16* alloc_fill(size_t n, uint32_t seed, float scale, float offs = 0.f) 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32, W = argc > 2 ? atoi(argv[2]) : 1024, S = argc > 3 ? atoi(argv[3]) : 100;
   const int C = 8, depth = 3, MR = (3 * depth + 2) * W;
-  if (!dl_persist_ok<bf16>(B, W, C, depth)) {
+  if (!dl_persist_ok<bf16>(B, W, C, depth, argc > 4 ? atoi(argv[4]) : 0)) {
     printf("shape not covered\n");
     return 1;
   }
@@ -75,6 +75,8 @@ int main(int argc, char** argv) {
   CK(hipMemset(p.prof, 0, 64 * 8));
   p.depth = depth; p.W = W; p.C = C; p.S = S; p.B = B; p.MR = MR; p.N = 1; p.b_off = 0; p.B_total = B;
   p.temperature = 1.0f;
+  p.spin_max = 1 << 20;
+  p.rows = argc > 4 ? atoi(argv[4]) : 0;   // rows per group: 0 = chosen by the batch (4 up to 32 rows at W 1024, 8 up to 64)
   p.seed = 1234;
   hipStream_t st;
   CK(hipStreamCreate(&st));

@@ -38,7 +38,8 @@ typedef unsigned int dp_u32x2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int DP_R = 4;     // rows per group
+constexpr int DP_R = 4;     // rows per group: 4, or 8 (round 4) when groups of 4 would need more workgroups than the chip has compute units
+                            // (W 1024: 33..64 rows, e.g. 32 samples under DiffLoss.sample's own guidance) - template parameter R of the kernel
 constexpr int DP_TC = 32;   // hidden columns per workgroup
 
 __device__ __forceinline__ float dp_silu(float x) { return x / (1.0f + expf(-x)); }
@@ -86,6 +87,9 @@ __device__ __forceinline__ float dp_wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+#ifndef VLG_DP_R8_LESS
+#define VLG_DP_R8_LESS 1   // resident phases given up at 8 rows per group
+#endif
 #ifndef VLG_DP_NRES2
 #define VLG_DP_NRES2 3   // register-resident GEMM phases at NKBW 2 (W 1024 bf16): 4 would spill
 #endif
@@ -143,14 +147,14 @@ struct DpRaw<float> {
 template <typename T>
 struct DpLds {
   size_t hfull, afull, red, outs, xs, cfs, wip, bip, ln, bias, bfin, wl, total;
-  __host__ __device__ DpLds(int W, int depth, int lds_phases = 0) {
+  __host__ __device__ DpLds(int W, int depth, int lds_phases = 0, int R = DP_R) {
     size_t o = 0;
-    hfull = o; o += (size_t)DP_R * W * sizeof(T);
-    afull = o; o += (size_t)DP_R * W * sizeof(T);
+    hfull = o; o += (size_t)R * W * sizeof(T);
+    afull = o; o += (size_t)R * W * sizeof(T);
     red = o; o += 4 * 2 * 256 * sizeof(float);
-    outs = o; o += DP_R * 16 * sizeof(float);
-    xs = o; o += DP_R * 16 * sizeof(float);
-    cfs = o; o += 64 * 8 * sizeof(float);
+    outs = o; o += R * 16 * sizeof(float);
+    xs = o; o += R * 16 * sizeof(float);
+    cfs = o; o += R * 16 * 8 * sizeof(float);
     wip = o; o += (size_t)W * 8 * sizeof(float);
     bip = o; o += (size_t)W * sizeof(float);
     ln = o; o += (size_t)depth * 2 * W * sizeof(T);
@@ -180,12 +184,18 @@ struct DpLds {
 // DEPTH > 0: the number of res blocks at compile time - the block loop is unrolled and the weight fragments of the first NRES GEMM
 // phases of a reverse step (w0[0], w2[0], w0[1], ...) stay in registers for the whole launch (a workgroup uses the same 32 columns of
 // every matrix in all S steps): no loads in front of those phases' polls, no wait behind them.  DEPTH = 0: runtime depth, all streamed.
-template <typename T, int NKBW, bool FULL, int DEPTH>
+// R: rows per group, 4 or 8.  R = 8: a wave runs the LayerNorm of rows wave and wave + 4 one after the other, rows 4..7 of a GEMM tile sit in
+// lanes 16..31 of the accumulators, waves 0 and 1 publish four rows each; one resident phase fewer (the modulation rows of two LayerNorm rows
+// take its registers) and no LDS-resident phase (the rows' streams take its LDS).
+template <typename T, int NKBW, bool FULL, int DEPTH, int R>
 __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
+  static_assert(R == 4 || R == 8, "rows per group");
+  constexpr int RW = R / 4;    // LayerNorm rows per wave = publishing waves
+  constexpr int HP = R / 2;    // guidance pairs per group
   // 32 * NKBW VGPRs per resident phase: all 2 * DEPTH phases at NKBW 1, VLG_DP_NRES2 of them at NKBW 2 (W 1024 bf16; 4 would spill)
-  constexpr int NRES = (DEPTH == 0 || NKBW > 2) ? 0 : (NKBW == 1 ? (2 * DEPTH < 8 ? 2 * DEPTH : 8) : VLG_DP_NRES2);
+  constexpr int NRES = (DEPTH == 0 || NKBW > 2) ? 0 : (NKBW == 1 ? (2 * DEPTH < 8 ? 2 * DEPTH : 8) : VLG_DP_NRES2 - VLG_DP_R8_LESS * (RW - 1));
   // ... and the next NLDS phases keep their fragments in LDS (64 KB per phase at NKBW 2), read back per lane right before the GEMM
-  constexpr int NLDS = (NRES > 0 && NRES < 2 * DEPTH && NKBW == 2) ? 1 : 0;
+  constexpr int NLDS = (R == 4 && NRES > 0 && NRES < 2 * DEPTH && NKBW == 2) ? 1 : 0;
   constexpr int EPV = 16 / (int)sizeof(T);
   constexpr int KBLK = 256 / (int)sizeof(T);
   const int W = p.W, C = p.C, S = p.S, MR = p.MR, depth = p.depth;
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   const int nkb = W / KBLK;
   const int nch = W / EPV;                           // 16-byte chunks per activation row
   extern __shared__ __attribute__((aligned(16))) char dp_smem[];
-  const DpLds<T> L(W, depth, NLDS);
+  const DpLds<T> L(W, depth, NLDS, R);
   T* hfull = reinterpret_cast<T*>(dp_smem + L.hfull);       // [R][W] residual stream of the group's rows
   T* afull = reinterpret_cast<T*>(dp_smem + L.afull);       // [R][W] current GEMM input (modulated LN output / mlp.0 output)
   float* red = reinterpret_cast<float*>(dp_smem + L.red);   // [4 waves][2 n-tiles][256]
@@ -223,22 +233,24 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     tile = (P % 8 == 0) ? (j % 8) * (P / 8) + j / 8 : j;
   }
   const int col0 = tile * DP_TC;
-  // local row j of the group <-> batch row.  Plain: rows 4 grp .. 4 grp + 3.  Guidance (n_half = B / 2 > 0, DiffLoss.sample's cfg,
-  // diffloss.py:37-41): the group serves the PAIRS 2 grp and 2 grp + 1 - local rows 0, 1 are their conditional rows (batch rows pair),
-  // local rows 2, 3 their unconditional partners (batch rows pair + n_half), so that a pair's two network outputs meet in one workgroup.
+  // local row j of the group <-> batch row.  Plain: rows R grp .. R grp + R - 1.  Guidance (n_half = B / 2 > 0, DiffLoss.sample's cfg,
+  // diffloss.py:37-41): the group serves the HP = R / 2 PAIRS HP grp .. HP grp + HP - 1 - local rows 0 .. HP - 1 are their conditional rows
+  // (batch rows pair), local rows HP .. R - 1 their unconditional partners (batch rows pair + n_half), so that a pair's two network
+  // outputs meet in one workgroup.
   const int n_half = p.n_half;
-  auto row_valid = [&](int j) { return n_half ? (2 * grp + (j & 1)) < n_half : (grp * DP_R + j) < p.B; };
-  auto row_batch = [&](int j) {   // batch row of local row j (an invalid local row maps to the group's first row: a valid address)
+  auto row_valid = [&](int j) __attribute__((always_inline)) { return n_half ? (HP * grp + (j % HP)) < n_half : (grp * R + j) < p.B; };
+  auto row_batch = [&](int j) __attribute__((always_inline)) {   // batch row of local row j (an invalid local row maps to the group's first row: a valid address)
     if (n_half) {
-      const int pair = row_valid(j) ? 2 * grp + (j & 1) : 2 * grp;
-      return pair + (row_valid(j) ? (j >> 1) : 0) * n_half;
+      const int pair = row_valid(j) ? HP * grp + (j % HP) : HP * grp;
+      return pair + (row_valid(j) ? (j / HP) : 0) * n_half;
     }
-    return row_valid(j) ? grp * DP_R + j : grp * DP_R;
+    return row_valid(j) ? grp * R + j : grp * R;
   };
   const int step_tok = p.state->step;
   unsigned epoch = 0;
   // exchange buffer: [parity][workgroup][NWD] 8-byte units {4 bytes of the tile, epoch tag}
-  constexpr int NWD = DP_R * DP_TC * (int)sizeof(T) / 4;     // 64 (bf16) / 128 (fp32) data words per published tile
+  constexpr int NWD = R * DP_TC * (int)sizeof(T) / 4;        // data words per published tile: 64 (bf16) / 128 (fp32) at 4 rows
+  constexpr int NWDW = NWD / RW;                             // ... per publishing wave
   const __amdgpu_buffer_rsrc_t rs_pay = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, (int)(2 * (size_t)gridDim.x * NWD * 8), 0x00020000);
 
   // ---- constants of the whole launch -> LDS -------------------------------------------------------------------------------
@@ -271,18 +283,21 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   // ---- helpers ------------------------------------------------------------------------------------------------------------
   // Loads that leave the chip's caches (this table, the gate rows, the step's noise) are issued right before a collect() and consumed
   // after it: collect() waits for its own loads, which return after every older one, so nothing else in the step waits on memory.
-  dp_u32x4_t vsc[NKBW], vsh[NKBW];       // rows of the next LayerNorm
-  dp_u32x4_t vsc2[NKBW], vsh2[NKBW];     // rows of the next reverse step's first LayerNorm (requested while the final layer's rows are still in use)
-  auto prefetch_mod = [&](dp_u32x4_t (&rsc)[NKBW], dp_u32x4_t (&rsh)[NKBW], const T* shift, const T* scale) {
-    const int grow = row_batch(wave);
-    const dp_u32x4_t* scg = reinterpret_cast<const dp_u32x4_t*>(scale + (size_t)grow * MR);
-    const dp_u32x4_t* shg = reinterpret_cast<const dp_u32x4_t*>(shift + (size_t)grow * MR);
+  dp_u32x4_t vsc[RW][NKBW], vsh[RW][NKBW];       // rows of the next LayerNorm (this wave's rows: wave, wave + 4)
+  dp_u32x4_t vsc2[RW][NKBW], vsh2[RW][NKBW];     // rows of the next reverse step's first LayerNorm (requested while the final layer's rows are still in use)
+  auto prefetch_mod = [&](dp_u32x4_t (&rsc)[RW][NKBW], dp_u32x4_t (&rsh)[RW][NKBW], const T* shift, const T* scale) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < NKBW; ++it) {
-      const int c = lane + 64 * it;
-      if (FULL || c < nch) {
-        rsc[it] = scg[c];
-        rsh[it] = shg[c];
+    for (int rw = 0; rw < RW; ++rw) {
+      const int grow = row_batch(wave + 4 * rw);
+      const dp_u32x4_t* scg = reinterpret_cast<const dp_u32x4_t*>(scale + (size_t)grow * MR);
+      const dp_u32x4_t* shg = reinterpret_cast<const dp_u32x4_t*>(shift + (size_t)grow * MR);
+#pragma unroll
+      for (int it = 0; it < NKBW; ++it) {
+        const int c = lane + 64 * it;
+        if (FULL || c < nch) {
+          rsc[rw][it] = scg[c];
+          rsh[rw][it] = shg[c];
+        }
       }
     }
   };
@@ -291,97 +306,102 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   // FROMX (the first LayerNorm of a reverse step): the row is not read from hfull but computed here from the step's x_t -
   // h[w] = rt(bias[w] + sum_c x[c] * wip[w][c])  (input_proj, diffloss.py:226; xs and wip_s are zero beyond C) - and stored to hfull
   // for the residual adds: no separate projection pass, no barrier between it and the statistics
-  auto ln_modulate = [&](const T* lnw, const T* lnb, auto FROMX) {
-    const int row = wave;
-    float hv[NKBW][EPV];
-    float s = 0.f;
-    float xr[8];
-    if constexpr (decltype(FROMX)::value) {
-      const int xrow = n_half ? (row & 1) : row;   // guidance: both rows of a pair are evaluated on the CONDITIONAL row's x_t (diffloss.py:38-39)
-      const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16 + 4);
+  auto ln_modulate = [&](const T* lnw, const T* lnb, auto FROMX) __attribute__((always_inline)) {
+    // the wave's rows one after the other (row = wave + 4 rw).  A row costs ~1.5 us of instruction issue (unpack, statistics, modulate, pack:
+    // ~700 instructions of one wave), not latency: running the two rows of an 8-row group side by side through the stages measured the same 3.0 us
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xr[c] = a[c];
-        xr[4 + c] = b[c];
+    for (int rw = 0; rw < RW; ++rw) {
+      const int row = wave + 4 * rw;
+      float hv[NKBW][EPV];
+      float s = 0.f;
+      float xr[8];
+      if constexpr (decltype(FROMX)::value) {
+        const int xrow = n_half ? (row % HP) : row;   // guidance: both rows of a pair are evaluated on the CONDITIONAL row's x_t (diffloss.py:38-39)
+        const dp_f32x4_t a = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16), b = *reinterpret_cast<const dp_f32x4_t*>(xs + xrow * 16 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          xr[c] = a[c];
+          xr[4 + c] = b[c];
+        }
       }
-    }
 #pragma unroll
-    for (int it = 0; it < NKBW; ++it) {
-      const int c = lane + 64 * it;
-      if (FULL || c < nch) {
-        if constexpr (decltype(FROMX)::value) {
-          float acc[EPV];
+      for (int it = 0; it < NKBW; ++it) {
+        const int c = lane + 64 * it;
+        if (FULL || c < nch) {
+          if constexpr (decltype(FROMX)::value) {
+            float acc[EPV];
 #pragma unroll
-          for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+            for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
 #pragma unroll
-          for (int cc = 0; cc < 8; ++cc) {          // channel-major: fmaf chain per element in channel order, as dl_step_proj_kernel
-            float wv[EPV];
+            for (int cc = 0; cc < 8; ++cc) {          // channel-major: fmaf chain per element in channel order, as dl_step_proj_kernel
+              float wv[EPV];
+#pragma unroll
+              for (int v4 = 0; v4 < EPV / 4; ++v4) {
+                const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(wip_s + (size_t)cc * W + (size_t)c * EPV + 4 * v4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[4 * v4 + u] = t4[u];
+              }
+#pragma unroll
+              for (int j = 0; j < EPV; ++j) acc[j] = fmaf(xr[cc], wv[j], acc[j]);
+            }
+            float bb[EPV];
 #pragma unroll
             for (int v4 = 0; v4 < EPV / 4; ++v4) {
-              const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(wip_s + (size_t)cc * W + (size_t)c * EPV + 4 * v4);
+              const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(bip_s + (size_t)c * EPV + 4 * v4);
 #pragma unroll
-              for (int u = 0; u < 4; ++u) wv[4 * v4 + u] = t4[u];
+              for (int u = 0; u < 4; ++u) bb[4 * v4 + u] = t4[u];
             }
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) acc[j] = fmaf(xr[cc], wv[j], acc[j]);
-          }
-          float bb[EPV];
-#pragma unroll
-          for (int v4 = 0; v4 < EPV / 4; ++v4) {
-            const dp_f32x4_t t4 = *reinterpret_cast<const dp_f32x4_t*>(bip_s + (size_t)c * EPV + 4 * v4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bb[4 * v4 + u] = t4[u];
+            for (int j = 0; j < EPV; ++j) hv[it][j] = dp_rt<T>(acc[j] + bb[j]);
+            reinterpret_cast<dp_u32x4_t*>(hfull + (size_t)row * W)[c] = dp_pack<T>(hv[it]);
+          } else {
+            dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(hfull + (size_t)row * W)[c], hv[it]);
           }
 #pragma unroll
-          for (int j = 0; j < EPV; ++j) hv[it][j] = dp_rt<T>(acc[j] + bb[j]);
-          reinterpret_cast<dp_u32x4_t*>(hfull + (size_t)row * W)[c] = dp_pack<T>(hv[it]);
-        } else {
-          dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(hfull + (size_t)row * W)[c], hv[it]);
-        }
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) s += hv[it][j];
-      }
-    }
-    s = dp_wave_sum(s);
-    const float mu = s / (float)W;
-    float d2 = 0.f;
-#pragma unroll
-    for (int it = 0; it < NKBW; ++it) {
-      const int c = lane + 64 * it;
-      if (FULL || c < nch) {
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-          const float d = hv[it][j] - mu;
-          d2 += d * d;
+          for (int j = 0; j < EPV; ++j) s += hv[it][j];
         }
       }
-    }
-    d2 = dp_wave_sum(d2);
-    const float rstd = 1.0f / sqrtf(d2 / (float)W + 1e-6f);
+      s = dp_wave_sum(s);
+      const float mu = s / (float)W;
+      float d2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < NKBW; ++it) {
-      const int c = lane + 64 * it;
-      if (FULL || c < nch) {
-        float sc[EPV], sh[EPV], lw[EPV], lb[EPV], o[EPV];
-        dp_unpack<T>(vsc[it], sc);
-        dp_unpack<T>(vsh[it], sh);
-        if (lnw) {
-          dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(lnw)[c], lw);
-          dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(lnb)[c], lb);
-        }
+      for (int it = 0; it < NKBW; ++it) {
+        const int c = lane + 64 * it;
+        if (FULL || c < nch) {
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-          float n = (hv[it][j] - mu) * rstd;
-          if (lnw) n = n * lw[j] + lb[j];
-          n = dp_rt<T>(n);
-          o[j] = n * (1.0f + sc[j]) + sh[j];
+          for (int j = 0; j < EPV; ++j) {
+            const float d = hv[it][j] - mu;
+            d2 += d * d;
+          }
         }
-        reinterpret_cast<dp_u32x4_t*>(afull + (size_t)row * W)[c] = dp_pack<T>(o);
+      }
+      d2 = dp_wave_sum(d2);
+      const float rstd = 1.0f / sqrtf(d2 / (float)W + 1e-6f);
+#pragma unroll
+      for (int it = 0; it < NKBW; ++it) {
+        const int c = lane + 64 * it;
+        if (FULL || c < nch) {
+          float sc[EPV], sh[EPV], lw[EPV], lb[EPV], o[EPV];
+          dp_unpack<T>(vsc[rw][it], sc);
+          dp_unpack<T>(vsh[rw][it], sh);
+          if (lnw) {
+            dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(lnw)[c], lw);
+            dp_unpack<T>(reinterpret_cast<const dp_u32x4_t*>(lnb)[c], lb);
+          }
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            float n = (hv[it][j] - mu) * rstd;
+            if (lnw) n = n * lw[j] + lb[j];
+            n = dp_rt<T>(n);
+            o[j] = n * (1.0f + sc[j]) + sh[j];
+          }
+          reinterpret_cast<dp_u32x4_t*>(afull + (size_t)row * W)[c] = dp_pack<T>(o);
+        }
       }
     }
   };
   // weight fragments of this workgroup's columns for this wave's K blocks (requested early: they do not depend on the activations)
-  auto load_w = [&](const T* wmat, int nrows, int c0, auto& bfx) {
+  auto load_w = [&](const T* wmat, int nrows, int c0, auto& bfx) __attribute__((always_inline)) {
     constexpr int NT = (int)(sizeof(bfx) / sizeof(bfx[0]));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       }
   };
   // red[wave][nt][256] = partial sums of afull[rows][K] . w[cols][K]^T over this wave's K blocks
-  auto gemm = [&](const auto& bfx) {
+  auto gemm = [&](const auto& bfx) __attribute__((always_inline)) {
     constexpr int NT = (int)(sizeof(bfx) / sizeof(bfx[0]));
     dp_f32x4_t acc[NT];
 #pragma unroll
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           dp_u32x4_t a = dp_u32x4_t{0u, 0u, 0u, 0u};
-          if (r < DP_R) a = *reinterpret_cast<const dp_u32x4_t*>(afull + (size_t)r * W + (size_t)kb * KBLK + (s2 * 4 + q) * EPV);
+          if (r < R) a = *reinterpret_cast<const dp_u32x4_t*>(afull + (size_t)r * W + (size_t)kb * KBLK + (s2 * 4 + q) * EPV);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) dp_mfma<T>(a, bfx[nt][i][s2], acc[nt]);
         }
@@ -421,18 +441,20 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[(wave * 2 + nt) * 256 + e * 64 + lane] = acc[nt][e];
   };
-  // element (row, col) of the reduced tile: accumulator layout col = lane & 15, row = 4 * (lane >> 4) + e  ->  rows 0..3 sit in lanes 0..15
-  auto reduced = [&](int nt, int row, int col) {
-    const int idx = row * 64 + col;   // e = row (row < 4), lane = col
+  // element (row, col) of the reduced tile: accumulator layout col = lane & 15, row = 4 * (lane >> 4) + e  ->  rows 0..3 sit in lanes 0..15,
+  // rows 4..7 in lanes 16..31
+  auto reduced = [&](int nt, int row, int col) __attribute__((always_inline)) {
+    const int idx = (row & 3) * 64 + 16 * (row >> 2) + col;   // e = row & 3, lane = 16 (row >> 2) + col
     return red[(0 * 2 + nt) * 256 + idx] + red[(1 * 2 + nt) * 256 + idx] + red[(2 * 2 + nt) * 256 + idx] + red[(3 * 2 + nt) * 256 + idx];
   };
   // Exchange, flag-in-data: every 4 bytes of a tile travel with the epoch in one 8-byte unit (single-copy atomic), so a consumer that
   // sees the tag sees the data - no store drain, no separate flag, no ordering between different stores needed.
-  // wave 0 publishes: lane l holds tile elements elem(0), elem(1) = one data word (bf16) / words l and l + 64 (fp32)
-  auto elem = [&](int j) { return sizeof(T) == 2 ? 2 * lane + j : lane + 64 * j; };
-  auto publish = [&](float v0, float v1) {
+  // waves < RW publish, wave w rows 4 w .. 4 w + 3 of the tile: lane l holds elements elem(0), elem(1) of those four rows = one data word
+  // (bf16) / words l and l + 64 (fp32)
+  auto elem = [&](int j) __attribute__((always_inline)) { return sizeof(T) == 2 ? 2 * lane + j : lane + 64 * j; };
+  auto publish = [&](float v0, float v1) __attribute__((always_inline)) {
     const int par = (int)(epoch & 1u);
-    const size_t base = ((size_t)par * gridDim.x + blockIdx.x) * NWD;
+    const size_t base = ((size_t)par * gridDim.x + blockIdx.x) * NWD + (size_t)wave * NWDW;
     if constexpr (sizeof(T) == 2) {
       const dp_u32x2_t u = dp_u32x2_t{dp_pack2(v0, v1), epoch};
       __builtin_amdgcn_raw_buffer_store_b64(u, rs_pay, (int)((base + lane) * 8), 0, 16);
@@ -443,14 +465,14 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   };
   // the workgroup gathers the P tiles of its group into dst [R][W]: 16-byte loads (two units each) past the L1, repeated until both tags
   // carry this epoch (bounded); false = a producer never arrived
-  auto collect = [&](T* dst, auto&& pre) -> bool {
+  auto collect = [&](T* dst, auto&& pre) __attribute__((always_inline)) -> bool {
     const int par = (int)(epoch & 1u);
     const size_t base = ((size_t)par * gridDim.x + (size_t)grp * P) * NWD;
     const int npair = P * NWD / 2;
     // one batch = four 16-byte loads per thread.  In the first batch the caller's loads for the next phase (weights, table rows) go out
     // in front of the first poll: the poll cannot succeed before the slowest producer's store has crossed the fabric anyway, and
     // the next GEMM needs the weights right after the barrier (measured both orders: this one is 0.7 us per reverse step faster).
-    auto batch = [&](int c0, auto with_pre) {
+    auto batch = [&](int c0, auto with_pre) __attribute__((always_inline)) {
       dp_u32x4_t v[4];
       bool need[4];
       if constexpr (decltype(with_pre)::value) pre();
@@ -495,7 +517,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   };
 
   // ---- x_T and the first input projection ------------------------------------------------------------------------------------
-  if (tid < DP_R * 16) {
+  if (tid < R * 16) {
     const int row = tid / 16, c = tid % 16;
     float v = 0.f;
     if (c < C && row_valid(row)) {
@@ -515,7 +537,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   dp_u32x4_t wres[NRES > 0 ? NRES : 1][2][NKBW][4];
   load_w(reinterpret_cast<const T*>(p.wf), 2 * C, 0, bff);
   // fragments of an LDS-resident phase <-> bf
-  auto lds_put = [&](int slot) {
+  auto lds_put = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) wl_s[((((size_t)slot * 2 + nt) * NKBW + i) * 4 + s2) * 256 + tid] = bf[nt][i][s2];
   };
-  auto lds_get = [&](int slot) {
+  auto lds_get = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -543,9 +565,10 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   } else {
     load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
   }
-  // wave 0: this lane's two elements of the published [R][32] tile
+  // publishing waves: this lane's two elements of the published [R][32] tile
   const int e0 = elem(0), e1 = elem(1);
-  const int prow0 = e0 / DP_TC, pc0 = e0 % DP_TC, prow1 = e1 / DP_TC, pc1 = e1 % DP_TC;
+  const int pwv = wave < RW ? wave : 0;
+  const int prow0 = 4 * pwv + e0 / DP_TC, pc0 = e0 % DP_TC, prow1 = 4 * pwv + e1 / DP_TC, pc1 = e1 % DP_TC;
   const int pg0 = row_batch(prow0), pg1 = row_batch(prow1);
   {
     const T* mod = reinterpret_cast<const T*>(p.mod_all) + (size_t)(S - 1) * p.B * MR;
@@ -553,7 +576,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   }
   // one res block (diffloss.py:99-129).  WA / WB: register-resident fragments of mlp.0 / mlp.2; SA / SB / SN: where mlp.0 / mlp.2 of this
   // block / mlp.0 of the next block live - 0 registers, 1 streamed into `bf` (requested at the start of the preceding exchange), 2 LDS
-  auto res_block = [&](int blk, int k, int i, const T* mod, const auto& WA, const auto& WB, auto SA, auto SB, auto SN, DdpmCoef& cf, float& nz) {
+  auto res_block = [&](int blk, int k, int i, const T* mod, const auto& WA, const auto& WB, auto SA, auto SB, auto SN, DdpmCoef& cf, float& nz) __attribute__((always_inline)) {
     const T* m0 = mod + (size_t)blk * 3 * W;          // [shift | scale | gate]  (diffloss.py:125)
     if (blk == 1) DP_STAMP(12);
     if (blk == 0) ln_modulate(ln_s, ln_s + W, std::true_type{});
@@ -568,20 +591,20 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     __syncthreads();
     if (blk == 0) DP_STAMP(2);
     epoch += 1;
-    if (wave == 0) {          // mlp.0: rt(silu(rt(acc + bias)))
+    if (wave < RW) {          // mlp.0: rt(silu(rt(acc + bias)))
       const float v0 = dp_rt<T>(reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc0]);
       const float v1 = dp_rt<T>(reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 0) * DP_TC + pc1]);
       publish(dp_silu(v0), dp_silu(v1));
     }
     if (blk == 0) DP_STAMP(3);
     typename DpRaw<T>::type g0r = 0, g1r = 0;      // gate values as stored (converted where they are used, not where they are requested)
-    alive = collect(afull, [&]() {
+    alive = collect(afull, [&]() __attribute__((always_inline)) {
       if constexpr (decltype(SB)::value == 1) load_w(reinterpret_cast<const T*>(p.w2[blk]), W, col0, bf);   // in flight during the exchange
-      if (wave == 0) {
+      if (wave < RW) {
         g0r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg0 * MR + 2 * W + col0 + pc0);
         g1r = *reinterpret_cast<const typename DpRaw<T>::type*>(m0 + (size_t)pg1 * MR + 2 * W + col0 + pc1);
         if (blk == 0) {
-          const int row = lane / 16, c = lane % 16;
+          const int row = 4 * wave + lane / 16, c = lane % 16;
           if (c < C && row_valid(row)) {
             cf = p.coef[i];
             const int b = row_batch(row);
@@ -593,9 +616,9 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     });
     if (blk == 0) DP_STAMP(4);
     if (!alive) return;
-    if (blk == 0 && wave == 0) {   // the step's coefficients and noise are in: park them in LDS, so that the DDPM update at the end of
+    if (blk == 0 && wave < RW) {   // the step's coefficients and noise are in: park them in LDS, so that the DDPM update at the end of
                                    // the step does not wait on whatever loads are in flight by then
-      float* o = cfs + lane * 8;
+      float* o = cfs + (wave * 64 + lane) * 8;
       o[0] = cf.sqrt_recip; o[1] = cf.sqrt_recipm1; o[2] = cf.coef1; o[3] = cf.coef2; o[4] = cf.min_log; o[5] = cf.max_log;
       o[6] = __int_as_float(cf.nonzero); o[7] = nz;
     }
@@ -605,7 +628,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     __syncthreads();
     if (blk == 0) DP_STAMP(5);
     epoch += 1;
-    if (wave == 0) {          // mlp.2 + gate + residual: h = rt(h + rt(gate * rt(acc + bias)))   (diffloss.py:128)
+    if (wave < RW) {          // mlp.2 + gate + residual: h = rt(h + rt(gate * rt(acc + bias)))   (diffloss.py:128)
       const float v0 = reduced(pc0 >> 4, prow0, pc0 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc0];
       const float v1 = reduced(pc1 >> 4, prow1, pc1 & 15) + bias_s[(blk * 2 + 1) * DP_TC + pc1];
       const float h0 = DT<T>::ld(hfull + (size_t)prow0 * W + col0 + pc0), h1 = DT<T>::ld(hfull + (size_t)prow1 * W + col0 + pc1);
@@ -613,7 +636,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       publish(h0 + dp_rt<T>(g0 * dp_rt<T>(v0)), h1 + dp_rt<T>(g1 * dp_rt<T>(v1)));
     }
     if (blk == 0) DP_STAMP(6);
-    alive = collect(hfull, [&]() {
+    alive = collect(hfull, [&]() __attribute__((always_inline)) {
       prefetch_mod(vsc, vsh, m0 + 3 * W, m0 + 4 * W);        // the next block's, or the final layer's, [shift | scale]
       if (blk + 1 < depth) {
         if constexpr (decltype(SN)::value == 1) load_w(reinterpret_cast<const T*>(p.w0[blk + 1]), W, col0, bf);
@@ -657,10 +680,12 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     {
       ln_modulate(nullptr, nullptr, std::false_type{});
 #pragma unroll
-      for (int it = 0; it < NKBW; ++it) {
-        vsc[it] = vsc2[it];
-        vsh[it] = vsh2[it];
-      }
+      for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+        for (int it = 0; it < NKBW; ++it) {
+          vsc[rw][it] = vsc2[rw][it];
+          vsh[rw][it] = vsh2[rw][it];
+        }
       __syncthreads();
       gemm(bff);
       __syncthreads();
@@ -670,14 +695,14 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       if constexpr (NRES == 0)
         if (k + 1 < S) load_w(reinterpret_cast<const T*>(p.w0[0]), W, col0, bf);
       // p_sample (gaussian_diffusion.py:254-332,376-420): learned-range variance, eps prediction, clip_denoised = False
-      if (tid < DP_R * 16) {
+      if (tid < R * 16) {
         const int row = tid / 16, c = tid % 16;
         if (c < C && row_valid(row)) {
           const float* cs = cfs + tid * 8;       // {sqrt_recip, sqrt_recipm1, coef1, coef2, min_log, max_log, nonzero, noise} of this step
           float eps = dp_rt<T>(reduced(0, row, c) + bfin_s[c]);
           const float v = dp_rt<T>(reduced(0, row, C + c) + bfin_s[C + c]);   // final layer outputs (eps | v)
           if (n_half) {   // forward_with_cfg (diffloss.py:240-248): eps = u + cfg (c - u) from the pair's two rows; variance, draw and x_t stay per row
-            const float ce = dp_rt<T>(reduced(0, row & 1, c) + bfin_s[c]), ue = dp_rt<T>(reduced(0, 2 + (row & 1), c) + bfin_s[c]);
+            const float ce = dp_rt<T>(reduced(0, row % HP, c) + bfin_s[c]), ue = dp_rt<T>(reduced(0, HP + row % HP, c) + bfin_s[c]);
             eps = dp_rt<T>(ue + dp_rt<T>(p.cfg * dp_rt<T>(ce - ue)));
           }
           const float xv = xs[row * 16 + c];
@@ -701,7 +726,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   // an exchange wait ran out: tell the host (vlg_gpt_status); system scope - the word lives in pinned host memory
   if (!alive && tid == 0 && p.fault) __hip_atomic_store(p.fault, kFaultDlPersist | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // ---- results: the workgroup of column tile 0 writes its group's rows (NaN when an exchange timed out) -------------------------
-  if (tile == 0 && tid < DP_R * 16) {
+  if (tile == 0 && tid < R * 16) {
     const int row = tid / 16, c = tid % 16;
     if (c < C && row_valid(row)) {
       const int b = row_batch(row);
@@ -715,8 +740,6 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
 
 }  // namespace
 
-size_t dl_persist_xbuf_bytes(int B, int W, int esz) { return (size_t)2 * cdiv(B, DP_R) * (W / DP_TC) * (DP_R * DP_TC * esz / 4) * 8; }
-
 namespace {
 // compute units of the current device: every workgroup of the launch must be resident at once (they wait for each other), and each takes a
 // whole CU (LDS >= 96 KB)
@@ -729,58 +752,97 @@ int dp_cu_count() {   // per device: a process may drive several
   if (dev < 64) cache[dev] = cus;
   return cus;
 }
+// rows per group of a launch: 4 while that fits one workgroup per CU, else 8; `want` (option dl_persist = 4 / 8) forces one of them; 0 = no fit
+int dp_group_rows(int B, int W, int want) {
+  if (B < 1 || W < DP_TC) return 0;
+  const int P = W / DP_TC, cus = dp_cu_count();
+  for (int R = 4; R <= 8; R += 4) {
+    if (want == 4 || want == 8) {
+      if (R != want) continue;
+    }
+    if (cdiv(B, R) * P <= cus) return R;
+  }
+  return 0;
+}
+// the kernel's NLDS for (R, depth, K blocks per wave)
+template <typename T>
+int dp_lds_phases(int R, int W, int depth) {
+  const int nkbw = cdiv(W * (int)sizeof(T) / 256, 4);
+  return (R == 4 && depth == 3 && nkbw == 2 && VLG_DP_NRES2 > 0 && VLG_DP_NRES2 < 6) ? 1 : 0;
+}
 }  // namespace
 
+// exchange buffer: [parity][workgroup][R * 32 elements as 8-byte units]; sized for either group height
+size_t dl_persist_xbuf_bytes(int B, int W, int esz) {
+  size_t best = 0;
+  for (int R = 4; R <= 8; R += 4) {
+    const size_t n = (size_t)2 * cdiv(B, R) * (W / DP_TC) * (R * DP_TC * esz / 4) * 8;
+    best = n > best ? n : best;
+  }
+  return best;
+}
+
 template <typename T>
-bool dl_persist_ok(int B, int W, int C, int depth) {
+bool dl_persist_ok(int B, int W, int C, int depth, int rows) {
   if (B < 1 || W < 256 || W % 256 != 0 || C < 1 || 2 * C > 16 || depth < 1 || depth > 8) return false;
   const int nkb = W * (int)sizeof(T) / 256;
-  return nkb <= 4 * DP_MAXKB && W / DP_TC <= 64 && DpLds<T>(W, depth, 1).total <= 150 * 1024 &&
-         cdiv(B, DP_R) * (W / DP_TC) <= dp_cu_count();   // one workgroup per CU: every participant of an exchange is resident
+  const int R = dp_group_rows(B, W, rows);   // one workgroup per CU: every participant of an exchange is resident
+  if (R == 8 && cdiv(nkb, 4) > 2 && depth != 3) return false;   // not instantiated (register budget)
+  return R > 0 && nkb <= 4 * DP_MAXKB && W / DP_TC <= 64 && DpLds<T>(W, depth, dp_lds_phases<T>(R, W, depth), R).total <= 150 * 1024;
 }
-template bool dl_persist_ok<float>(int, int, int, int);
-template bool dl_persist_ok<bf16>(int, int, int, int);
+template bool dl_persist_ok<float>(int, int, int, int, int);
+template bool dl_persist_ok<bf16>(int, int, int, int, int);
 
 namespace {
-template <typename T, int NKBW, bool FULL, int DEPTH>
-int dp_launch1(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
+template <typename T, int NKBW, bool FULL, int DEPTH, int R>
+int dp_launch2(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
   static bool attr[64] = {};   // the attribute is per device (a code object is loaded per device)
   int dev = 0;
   VLG_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr[dev]) {
-    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dl_persist_kernel<T, NKBW, FULL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    VLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dl_persist_kernel<T, NKBW, FULL, DEPTH, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     if (dev >= 0 && dev < 64) attr[dev] = true;
   }
-  dl_persist_kernel<T, NKBW, FULL, DEPTH><<<grid, 256, lds, st>>>(p);
+  dl_persist_kernel<T, NKBW, FULL, DEPTH, R><<<grid, 256, lds, st>>>(p);
   return VLG_OK;
 }
+template <typename T, int NKBW, bool FULL, int DEPTH>
+int dp_launch1(const DlPersist& p, int R, int grid, size_t lds, hipStream_t st) {
+  if constexpr (NKBW <= 2 || DEPTH == 3) {   // (8 rows x 4 K blocks per wave x runtime depth would spill 340 VGPRs: not built, dl_persist_ok says no)
+    if (R == 8) return dp_launch2<T, NKBW, FULL, DEPTH, 8>(p, grid, lds, st);
+  }
+  return dp_launch2<T, NKBW, FULL, DEPTH, 4>(p, grid, lds, st);
+}
 template <typename T, int NKBW, bool FULL>
-int dp_launch(const DlPersist& p, int grid, size_t lds, hipStream_t st) {
-  if (p.depth == 3) return dp_launch1<T, NKBW, FULL, 3>(p, grid, lds, st);   // the reference's depth (gpt_video_diff.py:77): resident weights
-  return dp_launch1<T, NKBW, FULL, 0>(p, grid, lds, st);
+int dp_launch(const DlPersist& p, int R, int grid, size_t lds, hipStream_t st) {
+  if (p.depth == 3) return dp_launch1<T, NKBW, FULL, 3>(p, R, grid, lds, st);   // the reference's depth (gpt_video_diff.py:77): resident weights
+  return dp_launch1<T, NKBW, FULL, 0>(p, R, grid, lds, st);
 }
 }  // namespace
 
 template <typename T>
 int dl_persist(const DlPersist& p, hipStream_t st) {
-  if (!dl_persist_ok<T>(p.B, p.W, p.C, p.depth)) {
-    set_error("dl_persist: shape B=%d W=%d C=%d depth=%d not covered", p.B, p.W, p.C, p.depth);
+  if (!dl_persist_ok<T>(p.B, p.W, p.C, p.depth, p.rows)) {
+    set_error("dl_persist: shape B=%d W=%d C=%d depth=%d (rows per group %d) not covered", p.B, p.W, p.C, p.depth, p.rows);
     return VLG_ERR_UNSUPPORTED;
   }
-  const int groups = cdiv(p.B, DP_R), P = p.W / DP_TC;
+  const int R = dp_group_rows(p.B, p.W, p.rows);
+  if (p.n_half && p.B != 2 * p.n_half) {
+    set_error("dl_persist: guidance pairs rows (b, b + B/2): n_half %d does not match %d rows", p.n_half, p.B);
+    return VLG_ERR_BAD_SHAPE;
+  }
+  const int groups = cdiv(p.B, R), P = p.W / DP_TC;
   VLG_HIP(hipMemsetAsync(p.xbuf, 0, dl_persist_xbuf_bytes(p.B, p.W, (int)sizeof(T)), st));   // epoch tags count within the launch
   // LDS: the activations plus padding up to > 80 KB so that no two workgroups share a CU (table row 1 of the hand-off forms is measured
   // for one workgroup per CU; correctness does not depend on it, the exchange latency does)
-  const int nkbw0 = cdiv(p.W * (int)sizeof(T) / 256, 4);
-  const int lds_phases = (p.depth == 3 && nkbw0 == 2 && VLG_DP_NRES2 > 0 && VLG_DP_NRES2 < 6) ? 1 : 0;   // = NLDS of the kernel that will run
-  size_t lds = DpLds<T>(p.W, p.depth, lds_phases).total;
+  size_t lds = DpLds<T>(p.W, p.depth, dp_lds_phases<T>(R, p.W, p.depth), R).total;   // = the carve-up of the kernel that will run
   if (lds < 96 * 1024) lds = 96 * 1024;
   const int nkbw = cdiv(p.W * (int)sizeof(T) / 256, 4);
   const bool full = (p.W * (int)sizeof(T)) % 1024 == 0 && nkbw != 3;
   int rc;
-  if (nkbw <= 1) rc = full ? dp_launch<T, 1, true>(p, groups * P, lds, st) : dp_launch<T, 1, false>(p, groups * P, lds, st);
-  else if (nkbw == 2) rc = full ? dp_launch<T, 2, true>(p, groups * P, lds, st) : dp_launch<T, 2, false>(p, groups * P, lds, st);
-  else rc = full ? dp_launch<T, 4, true>(p, groups * P, lds, st) : dp_launch<T, 4, false>(p, groups * P, lds, st);
+  if (nkbw <= 1) rc = full ? dp_launch<T, 1, true>(p, R, groups * P, lds, st) : dp_launch<T, 1, false>(p, R, groups * P, lds, st);
+  else if (nkbw == 2) rc = full ? dp_launch<T, 2, true>(p, R, groups * P, lds, st) : dp_launch<T, 2, false>(p, R, groups * P, lds, st);
+  else rc = full ? dp_launch<T, 4, true>(p, R, groups * P, lds, st) : dp_launch<T, 4, false>(p, R, groups * P, lds, st);
   if (rc != VLG_OK) return rc;
   VLG_HIP(hipGetLastError());
   return VLG_OK;

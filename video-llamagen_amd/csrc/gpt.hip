@@ -77,6 +77,7 @@ struct vlg_gpt {
   DevBuf pd_layers_dev;              // PdLayer[L]: weight pointers of every layer for the persistent kernel
   bool pd_fm = false;                // ... which are the fragment-major copies
   bool dl_persist_on = true;         // DiffLoss.sample as one persistent launch per token (diffloss_persist.hip) where the shape allows
+  int dl_rows = 0;                   // ... its rows per group: 0 = chosen by the batch, 4 / 8 forced (option dl_persist = 4 / 8)
   bool dtemb_ready = false;
 
   // per-generate state: activations, KV cache, step state and the stream the decode loop runs on
@@ -439,8 +440,10 @@ extern "C" int vlg_gpt_set_option(vlg_gpt_t* h, const char* key, int64_t value) 
     h->pd_rows = (int)value;
     return VLG_OK;
   }
-  if (!strcmp(key, "dl_persist")) {
+  if (!strcmp(key, "dl_persist")) {   // 0 off, 1 on, 4 / 8: on with that many rows per workgroup group
+    VLG_CHECK(value == 0 || value == 1 || value == 4 || value == 8, VLG_ERR_BAD_ARG, "dl_persist must be 0, 1, 4 or 8");
     h->dl_persist_on = value != 0;
+    h->dl_rows = value > 1 ? (int)value : 0;
     return VLG_OK;
   }
   set_error("unknown option %s", key);
@@ -888,7 +891,7 @@ struct Runner {
       set_error("cfg_iter != 1 pairs row b with row b + B/2 (diffloss.py:38-39): it needs an even batch, got %d rows", B);
       return VLG_ERR_BAD_SHAPE;
     }
-    if (h->dl_persist_on && dl_persist_ok<T>(B, Wd, C, dd)) {
+    if (h->dl_persist_on && dl_persist_ok<T>(B, Wd, C, dd, h->dl_rows)) {
       // all S reverse steps in one persistent launch (2 depth all-gathers per step between the workgroups of a 4-row group)
       DlPersist dp{};
       for (int blk = 0; blk < dd; ++blk) {
@@ -919,6 +922,7 @@ struct Runner {
       dp.spin_max = h->spin_max > 0 ? h->spin_max : (1 << 20);
       dp.n_half = n_half;
       dp.cfg = h->cfg_iter;
+      dp.rows = h->dl_rows;
       return dl_persist<T>(dp, st);
     }
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
@@ -1297,7 +1301,7 @@ int generate_impl(vlg_gpt* h, const void* d_cond, const float* d_mask, int B, in
                                    (uint64_t)(int64_t)sp.cfg_interval, fbits(sp.temperature), (uint64_t)(int64_t)sp.top_k, fbits(sp.top_p),
                                    (uint64_t)sp.sample_logits, sp.seed, (uint64_t)(uintptr_t)d_noise, (uint64_t)(uintptr_t)trace,
                                    (uint64_t)(uintptr_t)h->outbuf.p, (uint64_t)(uintptr_t)h->dtemb.p, (uint64_t)(uintptr_t)h->dadaln_bias.p,
-                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0)),
+                                   (uint64_t)((h->fuse_gemm ? 1 : 0) | (h->fuse_swiglu ? 2 : 0) | (h->pdecode ? 4 : 0) | (d_mask ? 32 : 0) | (h->dl_persist_on ? 128 : 0) | ((uint64_t)h->dl_rows << 8)),
                                    (uint64_t)(uintptr_t)h->dcoef_dev.p, (uint64_t)__builtin_bit_cast(uint32_t, h->cfg_iter), (uint64_t)(uintptr_t)r.st,
                                    (uint64_t)h->spin_max, (uint64_t)h->pd_rows, (uint64_t)h->pos_offset, (uint64_t)(uintptr_t)h->teach_ids, (uint64_t)(uintptr_t)h->teach_lat, (uint64_t)((h->weights_fm ? 1 : 0) | (h->act_fm ? 2 : 0))};
       {

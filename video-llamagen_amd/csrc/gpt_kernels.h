@@ -225,12 +225,13 @@ struct DlPersist {
   int spin_max;          // spin bound of every wait (default 1 << 20; option debug_spin_max)
   int n_half;            // 0, or B / 2: DiffLoss.sample's guidance pairs rows (b, b + B/2) as (conditional, unconditional)
   float cfg;             // ... with this scale (eps = u + cfg (c - u))
+  int rows;              // rows per group: 0 = 4 while one workgroup per CU holds the batch, else 8; 4 / 8 = that one (option dl_persist)
 };
 constexpr unsigned kFaultDlPersist = 0x444C0000u;   // 'DL' | reverse step index
 constexpr unsigned kFaultDecode = 0x50440000u;      // 'PD' | phase index
 size_t dl_persist_xbuf_bytes(int B, int W, int esz);
 template <typename T>
-bool dl_persist_ok(int B, int W, int C, int depth);
+bool dl_persist_ok(int B, int W, int C, int depth, int rows = 0);
 template <typename T>
 int dl_persist(const DlPersist& p, hipStream_t st);
 

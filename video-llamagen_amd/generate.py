@@ -68,7 +68,7 @@ def _run(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, noise,
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"time_attn", C.c_int64(1 if model.time_attn else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_swiglu", C.c_int64(1 if model.fuse_swiglu else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"fuse_gemm", C.c_int64(1 if model.fuse_gemm else 0)))
-        L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(1 if getattr(model, "dl_persist", True) else 0)))
+        L.check(L.lib().vlg_gpt_set_option(model._handle, b"dl_persist", C.c_int64(int(getattr(model, "dl_persist", True)))))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"pdecode", C.c_int64(1 if getattr(model, "pdecode", True) else 0)))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"debug_pos_offset", C.c_int64(int(getattr(model, "debug_pos_offset", 0)))))
         L.check(L.lib().vlg_gpt_set_option(model._handle, b"weights_fm", C.c_int64(1 if getattr(model, "weights_fm", True) else 0)))

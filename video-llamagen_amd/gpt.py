@@ -119,7 +119,8 @@ class Transformer:
         self.weights_fm = True   # decode GEMMs stream the fragment-major weight copies (one MFMA B fragment = 1 KB contiguous); bit-identical results
         self.act_fm = True       # the fused decode chain keeps its activations A-fragment-major; bit-identical results
         self.pd_rows = 0         # ... up to this many cache rows (0 = the library's measured default)
-        self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain
+        self.dl_persist = True   # DiffLoss.sample as one persistent launch per token (csrc/diffloss_persist.hip); False = per-step launch chain;
+                                 # 4 / 8 = persistent with that many rows per workgroup group (default: 4 up to 32 rows at W 1024, 8 up to 64)
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
     def eval(self):
