@@ -101,7 +101,7 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
                      const vlg_sampling_params* sp, const float* d_noise, int32_t* d_out_ids,
                      float* d_out_lat, float* d_trace, void* stream);
 
-/* Iteration-level batching for the request front-end (class-conditional token models; the role vLLM's model runner plays
+/* Iteration-level batching for the request front-end (token models, and the continuous-latent video models below; the role vLLM's model runner plays
  * in the reference's autoregressive/serve/, model_runner.py:845-886 + sampler.py:46-125).  A session owns `rows` KV-cache slots
  * of max_new_tokens + 1 positions; with sp->cfg_scale > 1 every slot carries its unconditional partner internally.
  *   session_step  advances EVERY slot by one token, each slot at its own position.  h_row_class[rows] (host memory):
@@ -112,7 +112,7 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
  *   session_read  copies the first n_tokens tokens of a slot to host memory (call it when the request is done, before
  *                 the slot is reused).                                                                               */
 int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp);
-/* Text-conditioned token models (t2i): puts ONE request's condition into a slot (ending whatever ran there) - d_cond fp32 [cls_token_num, caption_dim]
+/* Text-conditioned models (t2i, t2v): puts ONE request's condition into a slot (ending whatever ran there) - d_cond fp32 [cls_token_num, caption_dim]
  * (already * mask, sample_t2i.py:105-119), d_mask fp32 [cls_token_num] (1 = valid, left-padded) or NULL.  Positions 0 .. T-2 are
  * prefilled into the slot's KV rows (and uncond_embedding into its guidance partner's); the request then starts with code -3 in
  * session_step, whose first iteration runs the last condition token at position T-1 and samples token 0.  Waits for the prefill. */
@@ -132,6 +132,13 @@ int vlg_gpt_session_reserve(vlg_gpt_t* h, int32_t slot, int32_t n_tokens);
 int vlg_gpt_session_release(vlg_gpt_t* h, int32_t slot);
 int vlg_gpt_session_free_blocks(vlg_gpt_t* h, int32_t* n_free, int32_t* block_size);
 int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out);
+/* Sessions of the continuous-latent video models (model_type t2v, heads adapter2 and hidden/DiffLoss; beyond the reference, whose serving
+ * path stops at class-conditional images): the same calls - session_prefill puts a request's caption features into a slot, code -3
+ * starts it, -1 continues - with cfg_scale 1 (and cfg_iter 1): every slot produces ONE latent token [vae_embed_dim] per iteration at its
+ * own position (3-D RoPE row, KV rows, DiffLoss noise stream keyed by (seed, slot, token index)).  The hidden head needs the persistent
+ * DiffLoss sampler (option dl_persist, `rows` within what it covers).  session_read_latents copies the first n_tokens latents of a slot,
+ * fp32 [n_tokens, vae_embed_dim], to host memory.                                                                                      */
+int vlg_gpt_session_read_latents(vlg_gpt_t* h, int32_t row, int32_t n_tokens, float* h_out);
 int vlg_gpt_session_end(vlg_gpt_t* h);
 
 /* bytes the last generate() call moved algorithmically (weights + KV read/write + logits), for roofline */

@@ -349,6 +349,100 @@ def test_block_granular_kv_sessions_vs_reference_golden(golden):
     assert (run_t(e) == g["t2i_fp32_cfg_ids"]).all()
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_t2v_sessions_vs_reference_golden(golden, dt):
+    """Round 4: the iteration-level engine for the continuous-latent VIDEO models (vlg_gpt_session_* with model_type t2v, adapter2 head;
+    the reference's serving path stops at class-conditional images).  Every request's latents equal the REFERENCE's generate_t2v golden
+    (t2v.npz), whatever slot and iteration it starts in: three requests on 3 / 2 / 1 slots, a shorter request (a prefix of the golden), and
+    the block-granular KV cache with a pool that makes an admission wait."""
+    import video_llamagen_amd as V
+    from oracle import cases
+    from vlg_testutil import product_gpt, to_np
+    g = golden("t2v")
+    cfg = cases.TINY_T2V
+    m, _ = product_gpt(cfg, torch.float32 if dt == "fp32" else torch.bfloat16)
+    c, mk = cases.text_cond(2, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 4])
+    N = 3 * cfg["block_size"]
+    ref = g[f"t2v_{dt}_latents"]
+    tol = (3e-4 if dt == "fp32" else 8e-2) * max(1.0, np.abs(ref).max())
+    which = [0, 1, 0]
+
+    def run(engine, lens=(N, N, N)):
+        for i, w in enumerate(which):
+            engine.add_request(str(i), None, V.SamplingParams(temperature=1.0, max_tokens=lens[i]), prompt_embeds=torch.from_numpy(c[w]),
+                               emb_mask=torch.from_numpy(mk[w]))
+        outs, steps = {}, 0
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                assert o.outputs[0].token_ids == [] and o.outputs[0].latents is not None
+                outs[int(o.request_id)] = to_np(o.outputs[0].latents)
+            steps += 1
+            assert steps < 1000
+        return outs
+
+    for slots in (3, 2, 1):
+        outs = run(V.ContinuousLLMEngine(m, max_num_seqs=slots))
+        for i, w in enumerate(which):
+            assert outs[i].shape == (N, cfg["vae_embed_dim"])
+            assert np.abs(outs[i] - ref[w]).max() < tol, (slots, i, np.abs(outs[i] - ref[w]).max())
+    lens = (N, 20, 33)                                      # requests of different lengths side by side: prefixes of the golden
+    outs = run(V.ContinuousLLMEngine(m, max_num_seqs=2), lens)
+    for i, w in enumerate(which):
+        assert outs[i].shape[0] == lens[i] and np.abs(outs[i] - ref[w][:lens[i]]).max() < tol, i
+    # block-granular KV: 8 + 48 = 56 positions = 4 blocks of 16 per request; a pool of 1 + 8 blocks holds two requests, the third waits
+    e = V.ContinuousLLMEngine(m, max_num_seqs=3, kv_block_size=16, num_kv_blocks=1 + 8)
+    outs = run(e)
+    assert e.deferred > 0
+    for i, w in enumerate(which):
+        assert np.abs(outs[i] - ref[w]).max() < tol, i
+    with pytest.raises(ValueError):
+        V.ContinuousLLMEngine(m, cfg_scale=2.0, max_num_seqs=2)   # no transformer guidance for the continuous-latent sessions
+
+
+def test_t2v_diffloss_sessions_match_generate():
+    """Sessions of the DiffLoss (hidden) head: the persistent sampler with every slot at ITS token index (DlPersist::row_step).  The noise
+    stream is keyed by (seed, slot, token index), the key of generate_t2v's (seed, batch row, token index): B requests started together on B
+    slots reproduce generate_t2v(seed) row for row; with fewer slots than requests, the late request equals the row of the generate() call
+    that puts it at its slot's row.  fp32: both sides run the same kernels, tolerance for the fused-chain instance chosen by the row count."""
+    import video_llamagen_amd as V
+    from oracle import cases, detweights
+    from vlg_testutil import to_np
+    cfg = dict(cases.TINY_T2V_DIFF, num_sampling_steps=10, diffloss_w=256)
+    keys = ("dim", "n_layer", "n_head", "vocab_size", "block_size", "cls_token_num", "model_type", "caption_dim", "vae_embed_dim",
+            "num_frames", "t_downsample_size", "head", "diffloss_w", "diffloss_d", "num_sampling_steps")
+    m = V.Transformer(V.ModelArgs(**{k: cfg[k] for k in keys})).to("cuda", torch.float32).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in detweights.gpt_weights(cfg).items()}, strict=False)
+    c, mk = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5])
+    N = 12
+    sp = V.SamplingParams(temperature=0.9, max_tokens=N, seed=5)
+
+    def run(engine, order):
+        for i in order:
+            engine.add_request(str(i), None, sp, prompt_embeds=torch.from_numpy(c[i]), emb_mask=torch.from_numpy(mk[i]))
+        outs = {}
+        while engine.has_unfinished_requests():
+            for o in engine.step():
+                outs[int(o.request_id)] = to_np(o.outputs[0].latents)
+        return outs
+
+    ref = to_np(V.generate_t2v(m, torch.from_numpy(c), N, torch.from_numpy(mk), temperature=0.9, seed=5))
+    scale = max(1.0, np.abs(ref).max())
+    outs = run(V.ContinuousLLMEngine(m, max_num_seqs=3), [0, 1, 2])
+    for i in range(3):
+        assert np.isfinite(outs[i]).all() and np.abs(outs[i] - ref[i]).max() < 2e-4 * scale, (i, np.abs(outs[i] - ref[i]).max())
+    # two slots: requests 0 and 1 run first, request 2 then starts in slot 0 = row 0 of a generate() call over [2, 1]
+    outs = run(V.ContinuousLLMEngine(m, max_num_seqs=2), [0, 1, 2])
+    ref21 = to_np(V.generate_t2v(m, torch.from_numpy(c[[2, 1]]), N, torch.from_numpy(mk[[2, 1]]), temperature=0.9, seed=5))
+    assert np.abs(outs[0] - ref[0]).max() < 2e-4 * scale and np.abs(outs[1] - ref[1]).max() < 2e-4 * scale
+    assert np.abs(outs[2] - ref21[0]).max() < 2e-4 * scale
+    m.dl_persist = False                                     # without the persistent sampler the session is refused, loudly
+    e = V.ContinuousLLMEngine(m, max_num_seqs=2)
+    e.add_request("0", None, sp, prompt_embeds=torch.from_numpy(c[0]), emb_mask=torch.from_numpy(mk[0]))
+    with pytest.raises(RuntimeError):
+        e.step()
+    m.dl_persist = True
+
+
 def test_block_granular_kv_is_the_same_arithmetic():
     """Paging only changes where a cache row lives: sampled (top-k, temperature 1, guidance) bf16 sessions produce the same ids on 16-position
     blocks handed out of a tight pool as on contiguous slots."""

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     }
     return row_valid(j) ? grp * R + j : grp * R;
   };
-  const int step_tok = p.state->step;
+  // token index of a batch row: the launch's (StepState) or, in a session, the row's own (every slot at its own position)
+  const int step_uniform = p.state->step;
+  auto step_of = [&](int b) __attribute__((always_inline)) { return p.row_step ? p.row_step[b] : step_uniform; };
   unsigned epoch = 0;
   // exchange buffer: [parity][workgroup][NWD] 8-byte units {4 bytes of the tile, epoch tag}
   constexpr int NWD = R * DP_TC * (int)sizeof(T) / 4;        // data words per published tile: 64 (bf16) / 128 (fp32) at 4 rows
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     float v = 0.f;
     if (c < C && row_valid(row)) {
       const int b = n_half ? row_batch(row) % n_half : row_batch(row);   // one x_T draw per pair (diffloss.py:38-39)
+      const int step_tok = step_of(b);
       v = p.noise ? p.noise[(((size_t)step_tok * (S + 1)) * p.B_total + p.b_off + b) * C + c]
                   : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, 0u);
       v = DT<T>::rt(v);
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
           if (c < C && row_valid(row)) {
             cf = p.coef[i];
             const int b = row_batch(row);
+            const int step_tok = step_of(b);
             nz = p.noise ? p.noise[(((size_t)step_tok * (S + 1) + 1 + k) * p.B_total + p.b_off + b) * C + c]
                          : dp_philox_normal(p.seed, (uint32_t)c, (uint32_t)(p.b_off + b), (uint32_t)step_tok, (uint32_t)(1 + k));
           }
@@ -730,6 +734,7 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     const int row = tid / 16, c = tid % 16;
     if (c < C && row_valid(row)) {
       const int b = row_batch(row);
+      const int step_tok = step_of(b);
       const float v = alive ? xs[row * 16 + c] : __int_as_float(0x7fc00000);
       p.cur[(size_t)b * C + c] = v;
       p.out_lat[((size_t)b * p.N + step_tok) * C + c] = v;

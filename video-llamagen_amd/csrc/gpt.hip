@@ -780,10 +780,10 @@ struct Runner {
       VLG_TRY(norm_gemm(ln->x.as<T>(), final_norm, W<T>("vae_latent_adapter2.fc1.weight"), D, D, EPI_STORE, fa, Wfm<T>("vae_latent_adapter2.fc1.weight")));
       if (h->C <= 16)   // fc2 (N = C) + CFG combine + stores in one launch (3 before)
         return latent_out_fc2<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter2.fc2.weight"), ln->cur_lat.as<float>(),
-                                 out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, D, N, sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
+                                 out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, D, N, sp.cfg_scale, sp.cfg_interval, st, b0, Btot, row_step);
       VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter2.fc2.weight", ln->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
       return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
-                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
+                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot, row_step);
     }
     // hidden (DiffLoss): cond_embed(norm(x)) is the first op of the head (diffloss.py:227)
     fa.out = ln->d_cemb.as<T>();
@@ -804,7 +804,7 @@ struct Runner {
       VLG_TRY(linear(hl, "vae_latent_adapter2.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, D, ACT_GELU_TANH));
       VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter2.fc2.weight", ln->y.as<T>(), nullptr, Bp, h->C, D, ACT_NONE));
       return latent_head_finish<T>(ln->y.as<T>(), ln->cur_lat.as<float>(), out_lat + (size_t)b0 * N * h->C, trace, state(), B, Bp, h->C, N,
-                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot);
+                                   sp.cfg_scale, sp.cfg_interval, st, b0, Btot, row_step);
     }
     return diffloss_head(hl, sp, noise, out_lat, trace);
   }
@@ -819,6 +819,7 @@ struct Runner {
   // z = hl [B, D] (normed hidden of the last position).  All S steps are enqueued (and graph-captured) back to back.
   int diffloss_head(const T* z, const vlg_sampling_params& sp, const float* noise, float* out_lat, float* trace) {
     if (diffloss_fused_ok()) return diffloss_head_fused(z, sp, noise, out_lat, trace);
+    VLG_CHECK(row_step == nullptr, VLG_ERR_UNSUPPORTED, "sessions with the DiffLoss head need the persistent sampler (fused GEMM path)");
     VLG_CHECK(h->cfg_iter == 1.0f, VLG_ERR_UNSUPPORTED, "cfg_iter != 1: the unfused DiffLoss sampler (option fuse_gemm = 0 / widths the fused GEMM does not tile) has no guidance");
     const int Wd = h->dW, C = h->C, dd = h->dDepth, S = h->dS, MR = (3 * dd + 2) * Wd;
     const std::string p = "diffloss.net.";
@@ -923,8 +924,10 @@ struct Runner {
       dp.n_half = n_half;
       dp.cfg = h->cfg_iter;
       dp.rows = h->dl_rows;
+      dp.row_step = row_step;
       return dl_persist<T>(dp, st);
     }
+    VLG_CHECK(row_step == nullptr, VLG_ERR_UNSUPPORTED, "sessions with the DiffLoss head need the persistent sampler (option dl_persist, a shape it covers)");
     // LayerNorm + modulate inside the GEMM that consumes it (8 launches per reverse step) where the width fits its prologue
     const bool ln_in_gemm = gemm_ln_fused_ok<T>(B, Wd, Wd) && gemm_ln_fused_ok<T>(B, 2 * C, Wd) && !getenv("VLG_DIFFLOSS_NO_LN_FUSE");
     DdpmCoef none{};
@@ -1068,8 +1071,33 @@ struct Runner {
   }
 
   // one iteration of the request scheduler: every row at its own position (StepState::row_pos / row_step), inputs per row_cls
-  int session_step(const vlg_sampling_params& sp, const int32_t* row_cls, int32_t* out_ids) {
+  int session_step(const vlg_sampling_params& sp, const int32_t* row_cls, int32_t* out_ids, float* out_lat = nullptr) {
     const int D = h->D;
+    if (h->cfg.model_type == VLG_T2V) {
+      // continuous-latent models: every row's input is the adapter's image of the latent it produced last (decode_step's two forms); rows that
+      // start a request take the projected last condition token their prefill left in `pending`
+      afm = false;
+      if (h->fuse_gemm && h->C <= 16 && gemm_fused_ok<T>(Bp, D, D, false, EPI_STORE)) {
+        afm = afm_ok();
+        VLG_TRY(latent_in_fc1<T>(ln->cur_lat.as<float>(), W<T>("vae_latent_adapter.fc1.weight"), ln->t1.as<T>(), B, Bp, h->C, D, st));
+        FusedGemm f2;
+        f2.o_fm = afm;
+        f2.out = ln->x.as<T>();
+        f2.wfm = fm_on() ? Wfm<T>("vae_latent_adapter.fc2.weight") : nullptr;
+        VLG_TRY(gemm_fused<T>(ln->t1.as<T>(), W<T>("vae_latent_adapter.fc2.weight"), Bp, D, D, false, EPI_STORE, f2, st));
+      } else {
+        VLG_TRY(latent_to_rows<T>(ln->cur_lat.as<float>(), ln->latT.as<T>(), B, Bp, h->C, st));
+        VLG_TRY(linear(ln->latT.as<T>(), "vae_latent_adapter.fc1.weight", ln->t1.as<T>(), nullptr, Bp, D, h->C, ACT_GELU_TANH));
+        VLG_TRY(linear(ln->t1.as<T>(), "vae_latent_adapter.fc2.weight", ln->x.as<T>(), nullptr, Bp, D, D, ACT_NONE));
+      }
+      VLG_TRY(override_session_rows<T>(row_cls, reinterpret_cast<const T*>(pending), ln->x.as<T>(), Bp, D, st, afm ? D * (int)sizeof(T) / 64 : 0));
+      if (fused_decode_ok()) {
+        VLG_TRY(layers_fused());
+        return head_fused(sp, nullptr, nullptr, out_lat, nullptr);
+      }
+      VLG_TRY(layers(1, S - 1));
+      return head(ln->xn.as<T>(), sp, nullptr, nullptr, out_lat, nullptr);
+    }
     const T* cls_table = h->cfg.model_type == VLG_C2I ? W<T>("cls_embedding.embedding_table.weight") : nullptr;
     afm = afm_ok();
     VLG_TRY(gather_session_rows<T>(cls_table, h->cfg.num_classes + 1, W<T>("tok_embeddings.weight"), h->V, row_cls, ln->cur_tok.as<int32_t>(),
@@ -1377,6 +1405,7 @@ struct vlg_gpt::Session {
   bool cfg = false;
   vlg_sampling_params sp{};
   DevBuf row_pos, row_step, row_cls, out_ids;
+  DevBuf out_lat;                     // continuous-latent models: [R][maxN][C] fp32 instead of out_ids
   DevBuf maskbuf, pending;            // text-conditioned models: [R][Tc] fp32 condition masks; [Rp][D] input rows of starting slots
   std::vector<char> prefilled;        // slot has a condition in its KV rows and waits for its first step
   std::vector<int32_t> pos;           // host mirror: -1 = idle, else input position of the slot's next step
@@ -1443,6 +1472,11 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   VLG_HIP(hipMemset(ses->row_step.p, 0, nb));
   VLG_HIP(hipMemset(ses->ln.cur_tok.p, 0, (size_t)ses->Rp * sizeof(int32_t)));
   VLG_HIP(hipMemset(ses->out_ids.p, 0, (size_t)R * maxN * sizeof(int32_t)));
+  if (h->cfg.model_type == VLG_T2V) {
+    VLG_TRY(ses->out_lat.reserve((size_t)R * maxN * h->C * sizeof(float)));
+    VLG_HIP(hipMemset(ses->out_lat.p, 0, (size_t)R * maxN * h->C * sizeof(float)));
+    VLG_HIP(hipMemset(ses->ln.cur_lat.p, 0, (size_t)ses->Rp * h->C * sizeof(float)));   // idle rows feed a zero latent through the adapter
+  }
   ses->pos.assign(R, -1);
   ses->prefilled.assign(R, 0);
   ses->h_pos.assign(ses->Rp, 0);
@@ -1467,7 +1501,7 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = r.session_step(ses->sp, ses->row_cls.as<int32_t>(), ses->out_ids.as<int32_t>());
+    const int rc = r.session_step(ses->sp, ses->row_cls.as<int32_t>(), ses->out_ids.as<int32_t>(), ses->out_lat.as<float>());
     hipError_t ee = hipStreamEndCapture(st, &ses->graph);
     VLG_TRY(rc);
     VLG_HIP(ee);
@@ -1550,7 +1584,7 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
     r.pending = s.pending.p;
     r.pages = s.pages();
     r.pool_blocks = s.pool_blocks;
-    VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>()));
+    VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>(), s.out_lat.as<float>()));
   }
   // the host arrays are reused by the next call: the copies above must have been consumed
   VLG_HIP(hipStreamSynchronize(st));
@@ -1607,7 +1641,7 @@ int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float*
 extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask) {
   VLG_CHECK(h && d_cond, VLG_ERR_BAD_ARG, "vlg_gpt_session_prefill: null argument");
   VLG_CHECK(h->ses != nullptr, VLG_ERR_STATE, "no open session");
-  VLG_CHECK(h->cfg.model_type == VLG_T2I, VLG_ERR_UNSUPPORTED, "vlg_gpt_session_prefill is for text-conditioned token models");
+  VLG_CHECK(h->cfg.model_type == VLG_T2I || h->cfg.model_type == VLG_T2V, VLG_ERR_UNSUPPORTED, "vlg_gpt_session_prefill is for text-conditioned models");
   VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
   return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
 }
@@ -1677,8 +1711,19 @@ extern "C" int vlg_gpt_session_free_blocks(vlg_gpt_t* h, int32_t* n_free, int32_
 
 extern "C" int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp) {
   VLG_CHECK(h && sp && rows > 0 && max_new_tokens > 0, VLG_ERR_BAD_ARG, "vlg_gpt_session_begin: bad argument");
-  VLG_CHECK(h->cfg.head == VLG_HEAD_LOGITS && (h->cfg.model_type == VLG_C2I || h->cfg.model_type == VLG_T2I), VLG_ERR_UNSUPPORTED,
-            "sessions cover the token models: class-conditional (serve/sample_c2i.py) and text-conditioned");
+  if (h->cfg.model_type == VLG_T2V) {   // continuous-latent models (round 4; the reference's serve path stops at c2i): no guidance, as generate_t2v's shipped mode
+    VLG_CHECK(sp->cfg_scale <= 1.0f, VLG_ERR_UNSUPPORTED, "sessions of the continuous-latent models run without transformer guidance (cfg_scale 1)");
+    VLG_CHECK(h->cfg.head == VLG_HEAD_ADAPTER2 || h->cfg.head == VLG_HEAD_HIDDEN, VLG_ERR_UNSUPPORTED, "t2v sessions: adapter2 or hidden (DiffLoss) head");
+    if (h->cfg.head == VLG_HEAD_HIDDEN) {
+      VLG_CHECK(h->cfg_iter == 1.0f, VLG_ERR_UNSUPPORTED, "sessions of the DiffLoss head run without its guidance (cfg_iter 1): a pair would span two slots");
+      const bool ok = h->dl_persist_on && h->fuse_gemm &&
+                      (h->dtype == VLG_BF16 ? dl_persist_ok<bf16>(rows, h->dW, h->C, h->dDepth, h->dl_rows) : dl_persist_ok<float>(rows, h->dW, h->C, h->dDepth, h->dl_rows));
+      VLG_CHECK(ok, VLG_ERR_UNSUPPORTED, "sessions with the DiffLoss head need the persistent sampler: %d slots at width %d are outside what it covers", rows, h->dW);
+    }
+  } else {
+    VLG_CHECK(h->cfg.head == VLG_HEAD_LOGITS && (h->cfg.model_type == VLG_C2I || h->cfg.model_type == VLG_T2I), VLG_ERR_UNSUPPORTED,
+              "sessions cover the token models (class-conditional, serve/sample_c2i.py, and text-conditioned) and the continuous-latent video models");
+  }
   if (sp->cfg_scale > 1.0f && h->cfg.model_type == VLG_T2I)
     VLG_CHECK(h->Tc == 120, VLG_ERR_BAD_SHAPE, "CFG needs cls_token_num == 120 (uncond_embedding is [120, caption_dim], gpt.py:96)");
   VLG_CHECK(h->Tc + max_new_tokens <= h->npos, VLG_ERR_BAD_SHAPE, "max_new_tokens %d exceeds the RoPE table", max_new_tokens);
@@ -1700,6 +1745,17 @@ extern "C" int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens,
             row, n_tokens);
   VLG_HIP(hipStreamSynchronize(s.ln.st));
   VLG_HIP(hipMemcpy(h_out, s.out_ids.as<int32_t>() + (size_t)row * s.maxN, (size_t)n_tokens * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return VLG_OK;
+}
+
+extern "C" int vlg_gpt_session_read_latents(vlg_gpt_t* h, int32_t row, int32_t n_tokens, float* h_out) {
+  VLG_CHECK(h && h_out && h->ses != nullptr, VLG_ERR_BAD_ARG, "vlg_gpt_session_read_latents: bad argument / no open session");
+  vlg_gpt::Session& s = *h->ses;
+  VLG_CHECK(h->cfg.model_type == VLG_T2V && s.out_lat.p != nullptr, VLG_ERR_STATE, "vlg_gpt_session_read_latents: the session's model samples token ids (vlg_gpt_session_read)");
+  VLG_CHECK(row >= 0 && row < s.R && n_tokens >= 0 && n_tokens <= s.maxN, VLG_ERR_BAD_ARG, "vlg_gpt_session_read_latents: row %d / %d tokens out of range",
+            row, n_tokens);
+  VLG_HIP(hipStreamSynchronize(s.ln.st));
+  VLG_HIP(hipMemcpy(h_out, s.out_lat.as<float>() + (size_t)row * s.maxN * h->C, (size_t)n_tokens * h->C * sizeof(float), hipMemcpyDeviceToHost));
   return VLG_OK;
 }
 

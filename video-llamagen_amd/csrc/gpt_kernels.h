@@ -160,14 +160,15 @@ int latent_to_rows(const float* cur, T* out, int B, int Bp, int C, hipStream_t s
 // head output T [Bp, C] -> CFG combine (generate_video_diff.py:97-105) -> out_lat[b][step] fp32 and cur [B,C]
 template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp,
-                       int C, int N, float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
+                       int C, int N, float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0,
+                       const int32_t* row_step = nullptr);   // row_step: sessions - per-row token index instead of state->step
 
 // fused forms for the decode step (one workgroup per row; C <= 16): latent_to_rows + adapter.fc1 + GELU, and adapter2.fc2 + finish
 template <typename T>
 int latent_in_fc1(const float* cur, const T* w1, T* t1, int B, int Bp, int C, int D, hipStream_t st);
 template <typename T>
 int latent_out_fc2(const T* t1, const T* w2, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int D, int N,
-                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0);
+                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off = 0, int B_total = 0, const int32_t* row_step = nullptr);
 
 // ---- DiffLoss head pieces (diffloss.hip) ---------------------------------------------------------------------
 struct DdpmCoef {   // one respaced reverse step (gaussian_diffusion.py:232-252,288-292,334-339)
@@ -225,6 +226,7 @@ struct DlPersist {
   int spin_max;          // spin bound of every wait (default 1 << 20; option debug_spin_max)
   int n_half;            // 0, or B / 2: DiffLoss.sample's guidance pairs rows (b, b + B/2) as (conditional, unconditional)
   float cfg;             // ... with this scale (eps = u + cfg (c - u))
+  const int32_t* row_step;   // sessions: per-row token index (device array [B]) instead of state->step; null otherwise
   int rows;              // rows per group: 0 = 4 while one workgroup per CU holds the batch, else 8; 4 / 8 = that one (option dl_persist)
 };
 constexpr unsigned kFaultDlPersist = 0x444C0000u;   // 'DL' | reverse step index
@@ -305,6 +307,8 @@ int force_next_input(const StepState* state, const int32_t* ids, const float* la
 template <typename T>
 int gather_session_rows(const T* cls_table, int n_cls, const T* tok_table, int n_tok, const int32_t* row_cls, const int32_t* cur_tok,
                         const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks = 0);   // row_cls: >= 0 class id, -3 pending row, else token; out_nks > 0: out is A-fragment-major
+template <typename T>
+int override_session_rows(const int32_t* row_cls, const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks = 0);   // rows with row_cls = -3 take their pending row
 
 // sampler (sampler.hip) -----------------------------------------------------------------------
 // logits fp32 [Bp, V]; writes out_ids[b*N + step] (if out_ids), cur_tok[b] (and [b+B] when cfg_on),

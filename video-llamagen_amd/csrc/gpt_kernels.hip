@@ -1162,11 +1162,12 @@ template int latent_to_rows<bf16>(const float*, bf16*, int, int, int, hipStream_
 template <typename T>
 __global__ void latent_head_finish_kernel(const T* __restrict__ y, float* __restrict__ cur, float* __restrict__ out_lat,
                                           float* __restrict__ trace, const StepState* __restrict__ state, int B, int Bp, int C,
-                                          int N, float cfg_scale, int cfg_interval, int b_off, int B_total) {
+                                          int N, float cfg_scale, int cfg_interval, int b_off, int B_total,
+                                          const int32_t* __restrict__ row_step) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, cidx = i % C;
-  const int step = state->step;
+  const int step = row_step ? row_step[b] : state->step;   // sessions: every slot at its own token index
   float v = DT<T>::ld(y + (size_t)b * C + cidx);
   if (Bp > B) {
     // decode step i = step-1 of decode_n_tokens: cfg_flag off once i > cfg_interval >= 0 (generate.py:113-114)
@@ -1182,13 +1183,13 @@ __global__ void latent_head_finish_kernel(const T* __restrict__ y, float* __rest
 }
 template <typename T>
 int latent_head_finish(const T* y, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int N,
-                       float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total) {
+                       float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total, const int32_t* row_step) {
   latent_head_finish_kernel<T><<<cdiv(B * C, 256), 256, 0, st>>>(y, cur, out_lat, trace, state, B, Bp, C, N, cfg_scale, cfg_interval, b_off,
-                                                                 B_total > 0 ? B_total : B);
+                                                                 B_total > 0 ? B_total : B, row_step);
   return VLG_OK;
 }
-template int latent_head_finish<float>(const float*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
-template int latent_head_finish<bf16>(const bf16*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int);
+template int latent_head_finish<float>(const float*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int, const int32_t*);
+template int latent_head_finish<bf16>(const bf16*, float*, float*, float*, const StepState*, int, int, int, int, float, int, hipStream_t, int, int, const int32_t*);
 
 // ---- t2v decode step, latent side in two launches instead of six ---------------------------------------------------------
 // latent_in: cur fp32 [B,C] -> (rows duplicated for CFG) -> t1[m][d] = rt(gelu_tanh(rt(sum_c rt(cur[m % B][c]) * W1[d][c])))
@@ -1226,7 +1227,8 @@ template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void latent_out_fc2_kernel(const T* __restrict__ t1, const T* __restrict__ w2, float* __restrict__ cur,
                                                              float* __restrict__ out_lat, float* __restrict__ trace,
                                                              const StepState* __restrict__ state, int B, int Bp, int C, int D, int N,
-                                                             float cfg_scale, int cfg_interval, int b_off, int B_total) {
+                                                             float cfg_scale, int cfg_interval, int b_off, int B_total,
+                                                             const int32_t* __restrict__ row_step) {
   __shared__ float red[4][2][CMAX];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool pair = Bp > B;
@@ -1278,7 +1280,7 @@ __global__ __launch_bounds__(256) void latent_out_fc2_kernel(const T* __restrict
   __syncthreads();
   const int c = threadIdx.x;
   if (c >= C) return;
-  const int step = state->step;
+  const int step = row_step ? row_step[b] : state->step;   // sessions: every slot at its own token index
   float v = DT<T>::rt(red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
   if (pair) {
     const bool flag = !(cfg_interval > -1 && (step - 1) > cfg_interval);   // generate.py:113-114
@@ -1293,19 +1295,19 @@ __global__ __launch_bounds__(256) void latent_out_fc2_kernel(const T* __restrict
 }
 template <typename T>
 int latent_out_fc2(const T* t1, const T* w2, float* cur, float* out_lat, float* trace, const StepState* state, int B, int Bp, int C, int D, int N,
-                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total) {
+                   float cfg_scale, int cfg_interval, hipStream_t st, int b_off, int B_total, const int32_t* row_step) {
   if (C > 16) {
     set_error("latent_out_fc2: vae_embed_dim %d > 16", C);
     return VLG_ERR_UNSUPPORTED;
   }
   latent_out_fc2_kernel<T, 16><<<B, 256, 0, st>>>(t1, w2, cur, out_lat, trace, state, B, Bp, C, D, N, cfg_scale, cfg_interval, b_off,
-                                                  B_total > 0 ? B_total : B);
+                                                  B_total > 0 ? B_total : B, row_step);
   return VLG_OK;
 }
 template int latent_out_fc2<float>(const float*, const float*, float*, float*, float*, const StepState*, int, int, int, int, int, float, int,
-                                   hipStream_t, int, int);
+                                   hipStream_t, int, int, const int32_t*);
 template int latent_out_fc2<bf16>(const bf16*, const bf16*, float*, float*, float*, const StepState*, int, int, int, int, int, float, int,
-                                  hipStream_t, int, int);
+                                  hipStream_t, int, int, const int32_t*);
 
 // iteration-level batching: row m starts a request (row_cls[m] >= 0: its class embedding, the position-0 input of a c2i sequence)
 // or continues one (row_cls[m] < 0: the embedding of the token it sampled in the previous iteration)
@@ -1338,6 +1340,25 @@ template int gather_session_rows<float>(const float*, int, const float*, int, co
                                         hipStream_t, int);
 template int gather_session_rows<bf16>(const bf16*, int, const bf16*, int, const int32_t*, const int32_t*, const bf16*, bf16*, int, int, hipStream_t,
                                        int);
+
+// sessions of the continuous-latent models: the input rows come out of the latent adapter (every row: the latent it produced in the previous
+// iteration); a row that STARTS a request (row_cls = -3) or idles on the zero row takes its `pending` row instead - the projected last
+// condition token its prefill left, as for the text-conditioned token models
+template <typename T>
+__global__ __launch_bounds__(256) void override_session_rows_kernel(const int32_t* __restrict__ row_cls, const T* __restrict__ pending,
+                                                                    T* __restrict__ out, int D, int out_nks) {
+  const int m = blockIdx.x;
+  if (row_cls[m] != -3) return;
+  const T* src = pending + (size_t)m * D;
+  for (int i = threadIdx.x; i < D; i += 256) out[out_nks ? afm_index<T>(m, i, out_nks) : (size_t)m * D + i] = src[i];
+}
+template <typename T>
+int override_session_rows(const int32_t* row_cls, const T* pending, T* out, int rows, int D, hipStream_t st, int out_nks) {
+  override_session_rows_kernel<T><<<rows, 256, 0, st>>>(row_cls, pending, out, D, out_nks);
+  return VLG_OK;
+}
+template int override_session_rows<float>(const int32_t*, const float*, float*, int, int, hipStream_t, int);
+template int override_session_rows<bf16>(const int32_t*, const bf16*, bf16*, int, int, hipStream_t, int);
 
 __global__ void advance_state_kernel(StepState* s) {
   s->pos += 1;

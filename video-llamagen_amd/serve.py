@@ -61,6 +61,7 @@ class CompletionOutput:
     token_ids: List[int]
     text: str = ""
     finish_reason: Optional[str] = "length"
+    latents: Optional[torch.Tensor] = None           # continuous-latent video models: float [max_tokens, vae_embed_dim] (token_ids stays empty)
 
 
 @dataclasses.dataclass
@@ -199,7 +200,10 @@ class ContinuousLLMEngine:
         self.cfg_scale, self.cfg_interval, self.seed = float(cfg_scale), cfg_interval, seed
         self.cfg = self.cfg_scale > 1.0
         self.null_token = model.num_classes
-        self.text = model.model_type == "t2i"         # conditions are caption features: prefilled per slot, guidance partner internal
+        self.text = model.model_type in ("t2i", "t2v")   # conditions are caption features: prefilled per slot, guidance partner internal
+        self.latent = model.model_type == "t2v"       # continuous-latent video models: a request's output is latents [max_tokens, vae_embed_dim]
+        if self.latent and self.cfg:
+            raise ValueError("sessions of the continuous-latent models run without transformer guidance (cfg_scale 1), as generate_t2v's shipped mode")
         self.slots_n = max(1, max_num_seqs // 2 if (self.cfg and not self.text) else max_num_seqs)
         self.max_tokens = max_tokens
         self.kv_block_size, self.num_kv_blocks = int(kv_block_size), int(num_kv_blocks)
@@ -253,6 +257,13 @@ class ContinuousLLMEngine:
         with torch.cuda.device(self.model._device):
             L.check(L.lib().vlg_gpt_set_option(self.model._handle, b"kv_block", C.c_int64(self.kv_block_size)))
             L.check(L.lib().vlg_gpt_set_option(self.model._handle, b"kv_pool_blocks", C.c_int64(self.num_kv_blocks)))
+            if self.latent:   # the handle keeps options across calls: the session runs the mirror's current kernel switches, and no DiffLoss guidance
+                m = self.model
+                L.check(L.lib().vlg_gpt_set_option(m._handle, b"graph", C.c_int64(1 if m.use_graph else 0)))
+                L.check(L.lib().vlg_gpt_set_option(m._handle, b"fuse_gemm", C.c_int64(1 if m.fuse_gemm else 0)))
+                L.check(L.lib().vlg_gpt_set_option(m._handle, b"dl_persist", C.c_int64(int(getattr(m, "dl_persist", True)))))
+                if m._head_code() == L.VLG_HEAD_HIDDEN:
+                    L.check(L.lib().vlg_gpt_set_option_f64(m._handle, b"cfg_iter", C.c_double(1.0)))
             L.check(L.lib().vlg_gpt_session_begin(self.model._handle, self.slots_n, n, C.byref(c)))
         self._open, self._params, self.session_tokens = True, sp, n
 
@@ -359,6 +370,15 @@ class ContinuousLLMEngine:
             s[1] += 1
             r, done, partner = s
             if done == r.params.max_tokens:
+                if self.latent:
+                    cdim = self.model.config.vae_embed_dim
+                    fbuf = (C.c_float * (done * cdim))()
+                    L.check(L.lib().vlg_gpt_session_read_latents(self.model._handle, i, done, fbuf))
+                    lat = torch.frombuffer(fbuf, dtype=torch.float32).clone().view(done, cdim)
+                    outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, [], latents=lat)]))
+                    L.check(L.lib().vlg_gpt_session_release(self.model._handle, i))
+                    self.slots[i] = None
+                    continue
                 buf = (C.c_int32 * done)()
                 L.check(L.lib().vlg_gpt_session_read(self.model._handle, i, done, buf))
                 toks = list(buf)
