@@ -526,10 +526,17 @@ def test_session_and_t5_error_paths():
     from vlg_testutil import product_gpt
     sp = L.SamplingParams(cfg_scale=1.0, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=0, seed=0)
     t2v, _ = product_gpt(cases.TINY_T2V, torch.float32)
-    with pytest.raises(L.VlgError, match="token models"):
-        L.check(L.lib().vlg_gpt_session_begin(t2v._handle, 2, 4, C.byref(sp)))
+    spg = L.SamplingParams(cfg_scale=2.0, cfg_interval=-1, temperature=1.0, top_k=0, top_p=1.0, sample_logits=0, seed=0)
+    with pytest.raises(L.VlgError, match="without transformer guidance"):      # continuous-latent sessions: cfg_scale 1 only
+        L.check(L.lib().vlg_gpt_session_begin(t2v._handle, 2, 4, C.byref(spg)))
+    L.check(L.lib().vlg_gpt_session_begin(t2v._handle, 2, 4, C.byref(sp)))
+    with pytest.raises(L.VlgError, match="read_latents"):                      # ... and their results are latents, not ids
+        L.check(L.lib().vlg_gpt_session_read(t2v._handle, 0, 1, (C.c_int32 * 1)()))
+    L.check(L.lib().vlg_gpt_session_end(t2v._handle))
     t2i, _ = product_gpt(cases.TINY_T2I, torch.float32)
     L.check(L.lib().vlg_gpt_session_begin(t2i._handle, 2, 4, C.byref(sp)))
+    with pytest.raises(L.VlgError, match="samples token ids"):
+        L.check(L.lib().vlg_gpt_session_read_latents(t2i._handle, 0, 1, (C.c_float * 8)()))
     with pytest.raises(L.VlgError, match="no prefilled condition"):
         L.check(L.lib().vlg_gpt_session_step(t2i._handle, (C.c_int32 * 2)(-3, -2)))
     with pytest.raises(L.VlgError, match="does not fit"):

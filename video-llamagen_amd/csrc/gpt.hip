@@ -1741,6 +1741,7 @@ extern "C" int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class) {
 extern "C" int vlg_gpt_session_read(vlg_gpt_t* h, int32_t row, int32_t n_tokens, int32_t* h_out) {
   VLG_CHECK(h && h_out && h->ses != nullptr, VLG_ERR_BAD_ARG, "vlg_gpt_session_read: bad argument / no open session");
   vlg_gpt::Session& s = *h->ses;
+  VLG_CHECK(h->cfg.model_type != VLG_T2V, VLG_ERR_STATE, "vlg_gpt_session_read: the session's model produces latents (vlg_gpt_session_read_latents)");
   VLG_CHECK(row >= 0 && row < s.R && n_tokens >= 0 && n_tokens <= s.maxN, VLG_ERR_BAD_ARG, "vlg_gpt_session_read: row %d / %d tokens out of range",
             row, n_tokens);
   VLG_HIP(hipStreamSynchronize(s.ln.st));
