@@ -479,6 +479,36 @@ def main():
                 torch.cuda.empty_cache()
             else:
                 skipped.append("C4_ds16")
+            # the headline model behind the request front-end (round 4: sessions for the continuous-latent models): the B videos as B requests through
+            # ContinuousLLMEngine, 256 latent tokens each - one host round trip per iteration where generate_t2v replays a graph
+            if elapsed() + 8 <= a.budget_s and a.head != "hidden":
+                gs = build_gpt(V, a, device)
+                ns = 256
+                sps = V.SamplingParams(temperature=1.0, max_tokens=ns)
+
+                def serve_t2v():
+                    eng = V.ContinuousLLMEngine(gs, max_num_seqs=B, max_tokens=ns)
+                    for i in range(B):
+                        eng.add_request(str(i), None, sps, prompt_embeds=cond[i], emb_mask=mask[i])
+                    n = 0
+                    while eng.has_unfinished_requests():
+                        n += sum(int(o.outputs[0].latents.shape[0]) for o in eng.step())
+                    assert n == B * ns, n
+                serve_t2v()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                serve_t2v()
+                torch.cuda.synchronize()
+                dsv = time.perf_counter() - t
+                V.generate_t2v(gs, cond, 2, mask)
+                dgen = timed_t2v(gs, ns)
+                extras["C4_serving"] = {"workload": f"{a.gpt_model} t2v (adapter2 head) through ContinuousLLMEngine: {B} requests x {ns} latent tokens, bf16, one host round "
+                                                    f"trip per iteration; generate_t2v of the same {B} x {ns} tokens beside it", "sampling_s": dsv,
+                                        "tokens_per_s": B * ns / dsv, "generate_t2v_s": dgen}
+                del gs
+                torch.cuda.empty_cache()
+            else:
+                skipped.append("C4_serving")
             # the DiffLoss head (gpt_video_diff.py: 100 DDPM steps per token) in three 256-token windows of the 5120-token sequence - start,
             # middle, end (option debug_pos_offset: decode starts `offset` positions in, over a zero-filled cache prefix) - and the full-length
             # time they interpolate to (trapezoid over the windows' mid positions; the token step grows linearly with the context it attends to)
