@@ -1114,3 +1114,50 @@ def test_persistent_sampler_in_the_prefill_is_gated_too():
     assert not errs, errs
     for i in range(2):
         assert got[i] and all(torch.equal(o, want[i]) for o in got[i])
+
+
+def test_diffloss_session_iterations_are_gated_too():
+    """A session of the DiffLoss head launches the persistent sampler once per iteration (vlg_gpt_session_step): those launches take the
+    same process-wide gate as generate().  One thread serves requests through ContinuousLLMEngine, the other runs full generates on another
+    handle; nothing times out and both reproduce their single-threaded results."""
+    import threading
+    import video_llamagen_amd as V
+    ma, cfg, _ = _diff_model_w(torch.float32, 256, 10)
+    mb, _, _ = _diff_model_w(torch.float32, 256, 10)
+    ca, mka = cases.text_cond(3, cfg["cls_token_num"], cfg["caption_dim"], lens=[8, 2, 5])
+    cb, mkb = cases.text_cond(4, cfg["cls_token_num"], cfg["caption_dim"], lens=[3, 8, 1, 6], seed=9)
+    sp = V.SamplingParams(temperature=0.9, max_tokens=8, seed=5)
+
+    def serve():
+        eng = V.ContinuousLLMEngine(ma, max_num_seqs=2)
+        for k in range(3):
+            eng.add_request(str(k), None, sp, prompt_embeds=torch.from_numpy(ca[k]), emb_mask=torch.from_numpy(mka[k]))
+        outs = {}
+        while eng.has_unfinished_requests():
+            for o in eng.step():
+                outs[int(o.request_id)] = o.outputs[0].latents
+        return torch.stack([outs[k] for k in range(3)])
+
+    calls = [serve, lambda: V.generate_t2v(mb, torch.from_numpy(cb), 6, torch.from_numpy(mkb), seed=6).cpu()]
+    want = [f() for f in calls]
+    errs, got = [], [[], []]
+    go = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                go.wait()
+                for _ in range(6 if i == 0 else 12):
+                    got[i].append(calls[i]())
+                (ma, mb)[i].status()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert got[i] and all(torch.equal(o, want[i]) for o in got[i])

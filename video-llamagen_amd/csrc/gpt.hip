@@ -1498,6 +1498,13 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   r.pending = ses->pending.p;
   r.pages = ses->pages();
   r.pool_blocks = ses->pool_blocks;
+  // the DiffLoss head's per-handle tables (time embeddings of the respaced steps, fp32 modulation bias, DDPM coefficients on the device):
+  // generate() builds them on first use - a handle whose first call is a session needs them just the same
+  if (h->cfg.head == VLG_HEAD_HIDDEN && !h->dtemb_ready) {
+    VLG_TRY(r.build_time_table());
+    VLG_HIP(hipStreamSynchronize(st));
+  }
+  VLG_CHECK(h->cfg.head != VLG_HEAD_HIDDEN || (h->dtemb.p && h->dadaln_bias.p && h->dcoef_dev.p), VLG_ERR_STATE, "DiffLoss tables missing");
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1574,6 +1581,29 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   if (s.btab_dirty) {
     VLG_HIP(hipMemcpyAsync(s.btab.p, s.h_btab.data(), s.h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     s.btab_dirty = false;
+  }
+  // a session of the DiffLoss head launches the persistent sampler: the same process-wide gate as generate() (one persistent launch on the
+  // device at a time; held for this iteration, which ends with a stream synchronisation)
+  std::unique_lock<std::mutex> gate_lock;
+  struct GateRelease {
+    hipEvent_t ev = nullptr;
+    hipStream_t st = nullptr;
+    ~GateRelease() {
+      if (ev) (void)hipEventRecord(ev, st);
+    }
+  } gate_release;
+  static const bool gate_off = getenv("VLG_PERSIST_GATE") != nullptr && atoi(getenv("VLG_PERSIST_GATE")) == 0;
+  if (!gate_off && h->cfg.head == VLG_HEAD_HIDDEN && h->dl_persist_on) {
+    int dev = 0;
+    VLG_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64) {
+      PersistGate& g = persist_gate();
+      gate_lock = std::unique_lock<std::mutex>(g.mu);
+      if (!g.ev[dev]) VLG_HIP(hipEventCreateWithFlags(&g.ev[dev], hipEventDisableTiming));
+      VLG_HIP(hipStreamWaitEvent(st, g.ev[dev], 0));
+      gate_release.ev = g.ev[dev];
+      gate_release.st = st;
+    }
   }
   if (s.exec) {
     VLG_HIP(hipGraphLaunch(s.exec, st));
