@@ -375,6 +375,7 @@ class ContinuousLLMEngine:
                     fbuf = (C.c_float * (done * cdim))()
                     L.check(L.lib().vlg_gpt_session_read_latents(self.model._handle, i, done, fbuf))
                     lat = torch.frombuffer(fbuf, dtype=torch.float32).clone().view(done, cdim)
+                    self.model.status(sync=False)      # a time-out inside the persistent DiffLoss sampler surfaces here, not as NaN latents
                     outs.append(RequestOutput(r.request_id, None, r.prompt_token_ids, [CompletionOutput(0, [], latents=lat)]))
                     L.check(L.lib().vlg_gpt_session_release(self.model._handle, i))
                     self.slots[i] = None
