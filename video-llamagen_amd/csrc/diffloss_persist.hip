@@ -185,15 +185,22 @@ struct DpLds {
 // phases of a reverse step (w0[0], w2[0], w0[1], ...) stay in registers for the whole launch (a workgroup uses the same 32 columns of
 // every matrix in all S steps): no loads in front of those phases' polls, no wait behind them.  DEPTH = 0: runtime depth, all streamed.
 // R: rows per group, 4 or 8.  R = 8: a wave runs the LayerNorm of rows wave and wave + 4 one after the other, rows 4..7 of a GEMM tile sit in
-// lanes 16..31 of the accumulators, waves 0 and 1 publish four rows each; one resident phase fewer (the modulation rows of two LayerNorm rows
-// take its registers) and no LDS-resident phase (the rows' streams take its LDS).
+// lanes 16..31 of the accumulators, waves 0 and 1 publish four rows each; three resident phases as at 4 rows (LATE_MOD below frees their registers)
+// but no LDS-resident phase (the rows' streams take its LDS).
 template <typename T, int NKBW, bool FULL, int DEPTH, int R>
 __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
   static_assert(R == 4 || R == 8, "rows per group");
   constexpr int RW = R / 4;    // LayerNorm rows per wave = publishing waves
   constexpr int HP = R / 2;    // guidance pairs per group
+#ifndef VLG_DP_LATE_MOD
+#define VLG_DP_LATE_MOD 1
+#endif
+  // LATE_MOD (8 rows per group): no second register set for the next step's first modulation rows - they are requested after the final layer's
+  // LayerNorm has used the first set, in flight under the final GEMM and the DDPM update - and the 32 registers go to a third resident GEMM
+  // phase: 29.65 -> 29.20 us per reverse step at 64 rows (dl_persist_lab; -DVLG_DP_LATE_MOD=0 is the A/B build)
+  constexpr bool LATE_MOD = R == 8 && VLG_DP_LATE_MOD != 0;
   // 32 * NKBW VGPRs per resident phase: all 2 * DEPTH phases at NKBW 1, VLG_DP_NRES2 of them at NKBW 2 (W 1024 bf16; 4 would spill)
-  constexpr int NRES = (DEPTH == 0 || NKBW > 2) ? 0 : (NKBW == 1 ? (2 * DEPTH < 8 ? 2 * DEPTH : 8) : VLG_DP_NRES2 - VLG_DP_R8_LESS * (RW - 1));
+  constexpr int NRES = (DEPTH == 0 || NKBW > 2) ? 0 : (NKBW == 1 ? (2 * DEPTH < 8 ? 2 * DEPTH : 8) : VLG_DP_NRES2 - (VLG_DP_LATE_MOD ? 0 : VLG_DP_R8_LESS) * (RW - 1));
   // ... and the next NLDS phases keep their fragments in LDS (64 KB per phase at NKBW 2), read back per lane right before the GEMM
   constexpr int NLDS = (R == 4 && NRES > 0 && NRES < 2 * DEPTH && NKBW == 2) ? 1 : 0;
   constexpr int EPV = 16 / (int)sizeof(T);
@@ -645,8 +652,10 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
       if (blk + 1 < depth) {
         if constexpr (decltype(SN)::value == 1) load_w(reinterpret_cast<const T*>(p.w0[blk + 1]), W, col0, bf);
       } else if (k + 1 < S) {
-        const T* mn = reinterpret_cast<const T*>(p.mod_all) + (size_t)(i - 1) * p.B * MR;
-        prefetch_mod(vsc2, vsh2, mn, mn + W);
+        if constexpr (!LATE_MOD) {
+          const T* mn = reinterpret_cast<const T*>(p.mod_all) + (size_t)(i - 1) * p.B * MR;
+          prefetch_mod(vsc2, vsh2, mn, mn + W);
+        }
       }
     });
     if (blk == 0) DP_STAMP(7);
@@ -683,13 +692,20 @@ __global__ __launch_bounds__(256) void dl_persist_kernel(DlPersist p) {
     // final layer (diffloss.py:141-148): modulate(LN(h)) -> Linear W -> 2C, computed by every workgroup for its rows
     {
       ln_modulate(nullptr, nullptr, std::false_type{});
-#pragma unroll
-      for (int rw = 0; rw < RW; ++rw)
-#pragma unroll
-        for (int it = 0; it < NKBW; ++it) {
-          vsc[rw][it] = vsc2[rw][it];
-          vsh[rw][it] = vsh2[rw][it];
+      if constexpr (LATE_MOD) {   // requested here, behind the final layer's use of the same registers: in flight under the final GEMM and the DDPM update
+        if (k + 1 < S) {
+          const T* mn = reinterpret_cast<const T*>(p.mod_all) + (size_t)(i - 1) * p.B * MR;
+          prefetch_mod(vsc, vsh, mn, mn + W);
         }
+      } else {
+#pragma unroll
+        for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+          for (int it = 0; it < NKBW; ++it) {
+            vsc[rw][it] = vsc2[rw][it];
+            vsh[rw][it] = vsh2[rw][it];
+          }
+      }
       __syncthreads();
       gemm(bff);
       __syncthreads();
