@@ -789,6 +789,18 @@ def test_gpt_xl_full_size_first_tokens_vs_oracle():
         assert lat.shape == ref.shape == (2, 4, 8)
         assert np.abs(lat[:, :upto] - ref[:, :upto]).max() < tol * scale, (dt, np.abs(lat - ref).max(axis=(0, 2)))
         del m
+    # round 4: the SAME 36 layers at 17 rows - the fused chain's 16-row workgroups with a ragged second tile, the kernel instances of the
+    # benchmark's shards, at full depth - in bf16 against the oracle's bf16 emulation, teacher-forced on the oracle's own latents so that
+    # every one of the 5 steps is compared (tests/test_gpu_bench_instances.py does this on 2 layers for 700 steps)
+    B = 17
+    c17, mk17 = cases.text_cond(B, 120, 2048, lens=[1 + (7 * i) % 120 for i in range(B)])
+    ref17 = O.generate_t2v(O.GPTOracle(cfg, sd, "bf16"), c17, 5, mk17)
+    m, _ = product_gpt(cfg, torch.bfloat16, sd=sd)
+    lat17 = to_np(V.generate_t2v(m, torch.from_numpy(c17), 5, torch.from_numpy(mk17), teacher=torch.from_numpy(ref17)))
+    assert m.counter("chain_steps") > 0 and m.counter("pd_steps") == 0        # 17 rows: the launch chain, not the persistent step
+    err = np.abs(lat17 - ref17).max(axis=(0, 2))
+    assert np.isfinite(lat17).all() and (err < 4e-2 * max(1.0, np.abs(ref17).max())).all(), err
+    del m
 
 
 @pytest.mark.parametrize("hd,dts", [(32, ("fp32", "bf16")), (96, ("fp32", "bf16")), (128, ("fp32", "bf16")), (100, ("fp32",))])
