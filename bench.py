@@ -426,7 +426,7 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             traffic, tsrc = None, None
             try:   # HBM bytes per algorithmic byte measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction), see file
-                pmc_file = "r03_pmc_attn_fetch.json"   # re-collected at the end of round 3 (round 2's file: 1.0005-1.010, the same)
+                pmc_file = "r04_pmc_attn_fetch.json"   # re-collected in round 4 with tools/pmc_attn_fetch.py (rounds 2 and 3: 1.0005-1.010, the same)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 ratio = float(np.mean([r["traffic_over_algorithmic"] for r in pmc["rows"] if r["pos"] >= 1000]))
                 traffic, tsrc = ratio * by / n, "profiles/%s (FETCH_SIZE x2, ratio %.4f to algorithmic)" % (pmc_file, ratio)
