@@ -108,7 +108,9 @@ int vlg_gpt_generate(vlg_gpt_t* h, const void* d_cond, const float* d_emb_mask, 
  *                 >= 0  start a request with this class id in the slot (its first token is sampled by this step),
  *                 -3    (text-conditioned models) start the request whose condition vlg_gpt_session_prefill put into the slot,
  *                 -1    continue the slot's request,   -2  leave the slot idle.
- *                 The call returns after the step has run; tokens stay on the device.
+ *                 The call returns once the iteration is enqueued on the session's stream (its inputs are staged in pinned memory); tokens
+ *                 stay on the device.  session_read / session_read_latents / session_end wait for the stream; prefill, reserve and release are
+ *                 ordered behind earlier iterations by that stream.
  *   session_read  copies the first n_tokens tokens of a slot to host memory (call it when the request is done, before
  *                 the slot is reused).                                                                               */
 int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, const vlg_sampling_params* sp);

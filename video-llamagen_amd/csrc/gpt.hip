@@ -1410,6 +1410,13 @@ struct vlg_gpt::Session {
   std::vector<char> prefilled;        // slot has a condition in its KV rows and waits for its first step
   std::vector<int32_t> pos;           // host mirror: -1 = idle, else input position of the slot's next step
   std::vector<int32_t> h_pos, h_step, h_cls;
+  // per-iteration inputs travel through a ring of pinned staging slots [kStage][3][Rp], each guarded by an event: session_step returns once
+  // the iteration is enqueued and the host prepares the next one while the device runs (a slot is reused only after its copies were consumed)
+  static constexpr int kStage = 4;
+  int32_t* h_stage = nullptr;
+  hipEvent_t ev_stage[kStage] = {};
+  bool stage_used[kStage] = {};
+  int stage_i = 0;
   // block-granular cache (option kv_block): table [Rp][nblk_row] of pool block ids, 0 = the scratch block idle rows run on
   int bs_shift = 0, nblk_row = 0, pool_blocks = 0;
   DevBuf btab;
@@ -1431,6 +1438,9 @@ struct vlg_gpt::Session {
   ~Session() {
     if (exec) (void)hipGraphExecDestroy(exec);
     if (graph) (void)hipGraphDestroy(graph);
+    if (h_stage) (void)hipHostFree(h_stage);
+    for (hipEvent_t e : ev_stage)
+      if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -1575,15 +1585,31 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   }
   hipStream_t st = s.ln.st;
   const size_t nb = (size_t)s.Rp * sizeof(int32_t);
-  VLG_HIP(hipMemcpyAsync(s.row_pos.p, s.h_pos.data(), nb, hipMemcpyHostToDevice, st));
-  VLG_HIP(hipMemcpyAsync(s.row_step.p, s.h_step.data(), nb, hipMemcpyHostToDevice, st));
-  VLG_HIP(hipMemcpyAsync(s.row_cls.p, s.h_cls.data(), nb, hipMemcpyHostToDevice, st));
-  if (s.btab_dirty) {
+  static const bool sync_steps = getenv("VLG_SESSION_SYNC") != nullptr && atoi(getenv("VLG_SESSION_SYNC")) != 0;   // A/B knob: wait for every iteration
+  bool wait_here = sync_steps;
+  if (s.h_stage == nullptr) {
+    VLG_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_stage), (size_t)vlg_gpt::Session::kStage * 3 * nb, hipHostMallocDefault));
+    for (hipEvent_t& e : s.ev_stage) VLG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int slot = s.stage_i % vlg_gpt::Session::kStage;
+  if (s.stage_used[slot]) VLG_HIP(hipEventSynchronize(s.ev_stage[slot]));   // the iteration that last used this slot has consumed it
+  int32_t* stg = s.h_stage + (size_t)slot * 3 * s.Rp;
+  memcpy(stg, s.h_pos.data(), nb);
+  memcpy(stg + s.Rp, s.h_step.data(), nb);
+  memcpy(stg + 2 * (size_t)s.Rp, s.h_cls.data(), nb);
+  VLG_HIP(hipMemcpyAsync(s.row_pos.p, stg, nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipMemcpyAsync(s.row_step.p, stg + s.Rp, nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipMemcpyAsync(s.row_cls.p, stg + 2 * (size_t)s.Rp, nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipEventRecord(s.ev_stage[slot], st));
+  s.stage_used[slot] = true;
+  s.stage_i += 1;
+  if (s.btab_dirty) {   // the block table is copied from pageable host memory that reserve / release keep editing: wait for it below
     VLG_HIP(hipMemcpyAsync(s.btab.p, s.h_btab.data(), s.h_btab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     s.btab_dirty = false;
+    wait_here = true;
   }
   // a session of the DiffLoss head launches the persistent sampler: the same process-wide gate as generate() (one persistent launch on the
-  // device at a time; held for this iteration, which ends with a stream synchronisation)
+  // device at a time; held while this iteration is enqueued, the event recorded behind it is what the next holder waits for)
   std::unique_lock<std::mutex> gate_lock;
   struct GateRelease {
     hipEvent_t ev = nullptr;
@@ -1616,8 +1642,9 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
     r.pool_blocks = s.pool_blocks;
     VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>(), s.out_lat.as<float>()));
   }
-  // the host arrays are reused by the next call: the copies above must have been consumed
-  VLG_HIP(hipStreamSynchronize(st));
+  // the iteration is enqueued; its inputs sit in a pinned staging slot of their own, so the host may go on (session_read / session_end wait
+  // for the stream, everything else a caller does with the session is ordered behind it on the same stream)
+  if (wait_here) VLG_HIP(hipStreamSynchronize(st));
   return VLG_OK;
 }
 }  // namespace
@@ -1720,7 +1747,7 @@ extern "C" int vlg_gpt_session_release(vlg_gpt_t* h, int32_t slot) {
   s.pos[slot] = -1;
   s.prefilled[slot] = 0;
   if (!s.paged()) return VLG_OK;
-  // the step that last used these blocks has been waited for (session_step synchronises its stream before it returns)
+  // the steps that used these blocks are ahead on the session's stream of whatever a later owner of the blocks will enqueue there
   for (int r = 0; r < (s.cfg ? 2 : 1); ++r)
     for (int j = 0; j < s.nblk_row; ++j) {
       int32_t& e = s.h_btab[(size_t)(slot + r * s.R) * s.nblk_row + j];
