@@ -502,8 +502,8 @@ def main():
                 dsv = time.perf_counter() - t
                 V.generate_t2v(gs, cond, 2, mask)
                 dgen = timed_t2v(gs, ns)
-                extras["C4_serving"] = {"workload": f"{a.gpt_model} t2v (adapter2 head) through ContinuousLLMEngine: {B} requests x {ns} latent tokens, bf16, {B} one-request "
-                                                    f"prefills; generate_t2v of the same {B} x {ns} tokens beside it", "sampling_s": dsv,
+                extras["C4_serving"] = {"workload": f"{a.gpt_model} t2v (adapter2 head) through ContinuousLLMEngine: {B} requests x {ns} latent tokens, bf16, one batched "
+                                                    f"prefill; generate_t2v of the same {B} x {ns} tokens beside it", "sampling_s": dsv,
                                         "tokens_per_s": B * ns / dsv, "generate_t2v_s": dgen}
                 del gs
                 torch.cuda.empty_cache()

@@ -119,6 +119,9 @@ int vlg_gpt_session_begin(vlg_gpt_t* h, int32_t rows, int32_t max_new_tokens, co
  * prefilled into the slot's KV rows (and uncond_embedding into its guidance partner's); the request then starts with code -3 in
  * session_step, whose first iteration runs the last condition token at position T-1 and samples token 0.  Waits for the prefill. */
 int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask);
+/* The same for n requests that land in CONSECUTIVE slots first_slot .. first_slot + n - 1 (d_cond [n, cls_token_num, caption_dim], d_mask
+ * [n, cls_token_num] or NULL): one prefill of n x (cls_token_num - 1) rows instead of n one-request prefills. */
+int vlg_gpt_session_prefill_batch(vlg_gpt_t* h, int32_t first_slot, int32_t n, const float* d_cond, const float* d_mask);
 int vlg_gpt_session_step(vlg_gpt_t* h, const int32_t* h_row_class);
 /* Block-granular KV cache (the role of vLLM's block manager behind serve/gpt_model.py:181-224).  With option "kv_block" = BS > 0
  * (a power of two, 8..1024; set before session_begin) the session's cache is a pool of "kv_pool_blocks" blocks of BS positions

@@ -60,7 +60,7 @@ SYMBOLS = [
     "vlg_last_error", "vlg_version",
     "vlg_gpt_create", "vlg_gpt_destroy", "vlg_gpt_load_tensor", "vlg_gpt_generate",
     "vlg_gpt_last_algorithmic_bytes", "vlg_gpt_graphs_built", "vlg_gpt_set_option", "vlg_gpt_attn_timing", "vlg_gpt_attn_event_overhead",
-    "vlg_gpt_session_begin", "vlg_gpt_session_prefill", "vlg_gpt_session_step", "vlg_gpt_session_read", "vlg_gpt_session_read_latents", "vlg_gpt_session_end",
+    "vlg_gpt_session_begin", "vlg_gpt_session_prefill", "vlg_gpt_session_prefill_batch", "vlg_gpt_session_step", "vlg_gpt_session_read", "vlg_gpt_session_read_latents", "vlg_gpt_session_end",
     "vlg_gpt_session_reserve", "vlg_gpt_session_release", "vlg_gpt_session_free_blocks", "vlg_gpt_set_option_f64", "vlg_gpt_set_teacher", "vlg_gpt_status", "vlg_gpt_counter",
     "vlg_rmsnorm", "vlg_linear", "vlg_rope_table", "vlg_sample", "vlg_attn_decode",
     "vlg_vq_create", "vlg_vq_destroy", "vlg_vq_load_tensor", "vlg_vq_decode_code", "vlg_vq_argmin",

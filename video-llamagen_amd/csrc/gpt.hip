@@ -1654,18 +1654,21 @@ namespace {
 // through the prefill kernels (slab GEMMs, masked causal attention) against the slot's cache rows; the projected LAST condition token
 // is kept as the slot's pending input row, so the step that samples token 0 is an ordinary iteration of the batch at position Tc-1.
 template <typename T>
-int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float* d_mask) {
+int session_prefill_impl(vlg_gpt* h, int slot, int n, const float* d_cond, const float* d_mask) {   // slots slot .. slot + n - 1
   vlg_gpt::Session& s = *h->ses;
   const int Tc = h->Tc, D = h->D, cd = h->cd;
   hipStream_t st = s.ln.st;
   float* mrow = s.maskbuf.as<float>() + (size_t)slot * Tc;
-  if (s.paged()) VLG_CHECK(s.reserved[slot] >= Tc, VLG_ERR_STATE, "slot %d: reserve its KV blocks first (vlg_gpt_session_reserve)", slot);
-  s.pos[slot] = -1;   // arguments are valid: whatever ran in the slot is over, the caller reuses it (its tokens were read with session_read)
+  if (s.paged())
+    for (int i = 0; i < n; ++i)
+      VLG_CHECK(s.reserved[slot + i] >= Tc, VLG_ERR_STATE, "slot %d: reserve its KV blocks first (vlg_gpt_session_reserve)", slot + i);
+  // arguments are valid: whatever ran in the slots is over, the caller reuses them (their tokens were read with session_read)
+  for (int i = 0; i < n; ++i) s.pos[slot + i] = -1;
   if (d_mask) {
-    VLG_HIP(hipMemcpyAsync(mrow, d_mask, (size_t)Tc * sizeof(float), hipMemcpyDeviceToDevice, st));
+    VLG_HIP(hipMemcpyAsync(mrow, d_mask, (size_t)n * Tc * sizeof(float), hipMemcpyDeviceToDevice, st));
   } else {
-    std::vector<float> ones((size_t)Tc, 1.0f);
-    VLG_HIP(hipMemcpyAsync(mrow, ones.data(), (size_t)Tc * sizeof(float), hipMemcpyHostToDevice, st));
+    std::vector<float> ones((size_t)n * Tc, 1.0f);
+    VLG_HIP(hipMemcpyAsync(mrow, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, st));
     VLG_HIP(hipStreamSynchronize(st));
   }
   if (s.paged()) {
@@ -1676,31 +1679,38 @@ int session_prefill_impl(vlg_gpt* h, int slot, const float* d_cond, const float*
     }
   }
   for (int pass = 0; pass < (s.cfg ? 2 : 1); ++pass) {
-    Runner<T> r{h, &s.ln, st, 1, 1, s.maxN, s.S, 0, 1, mrow};
+    Runner<T> r{h, &s.ln, st, n, n, s.maxN, s.S, 0, n, mrow};
     r.kv_row0 = slot + pass * s.R;
     r.kv_rows = s.Rp;
     r.pages = s.pages(r.kv_row0);
     r.pool_blocks = s.pool_blocks;
     VLG_TRY(set_state(r.state(), 0, 0, st));
-    // pass 0: the request's caption features; pass 1: uncond_embedding (generate.py:138-139)
-    VLG_TRY(build_text_cond<T>(d_cond, r.template W<T>("cls_embedding.uncond_embedding"), s.ln.condT.as<T>(), pass == 0 ? 1 : 0, 1, Tc, cd, st));
-    VLG_TRY(r.linear(s.ln.condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", s.ln.t1.as<T>(), nullptr, Tc, D, cd, ACT_GELU_TANH));
-    VLG_TRY(r.linear(s.ln.t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", s.ln.x.as<T>(), nullptr, Tc, D, D, ACT_NONE));
-    VLG_TRY(take_last_rows<T>(s.ln.x.as<T>(), s.pending.as<T>() + (size_t)r.kv_row0 * D, 1, Tc, D, st));
+    // pass 0: the requests' caption features; pass 1: uncond_embedding (generate.py:138-139)
+    VLG_TRY(build_text_cond<T>(d_cond, r.template W<T>("cls_embedding.uncond_embedding"), s.ln.condT.as<T>(), pass == 0 ? n : 0, n, Tc, cd, st));
+    VLG_TRY(r.linear(s.ln.condT.as<T>(), "cls_embedding.cap_proj.fc1.weight", s.ln.t1.as<T>(), nullptr, n * Tc, D, cd, ACT_GELU_TANH));
+    // the projected condition rows [n][Tc][D]: the last of each slot is kept as its pending input, the others run through the layers
+    T* proj = n > 1 ? s.ln.xn.as<T>() : s.ln.x.as<T>();
+    VLG_TRY(r.linear(s.ln.t1.as<T>(), "cls_embedding.cap_proj.fc2.weight", proj, nullptr, n * Tc, D, D, ACT_NONE));
+    VLG_TRY(take_last_rows<T>(proj, s.pending.as<T>() + (size_t)r.kv_row0 * D, n, Tc, D, st));
+    if (n > 1) VLG_TRY(drop_last_rows<T>(proj, s.ln.x.as<T>(), n, Tc, D, st));   // [n][Tc - 1][D], what layers(Tc - 1, ...) walks
     if (Tc > 1) VLG_TRY(r.layers(Tc - 1, Tc - 2));
   }
   VLG_HIP(hipStreamSynchronize(st));
-  s.prefilled[slot] = 1;
+  for (int i = 0; i < n; ++i) s.prefilled[slot + i] = 1;
   return VLG_OK;
 }
 }  // namespace
 
-extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask) {
+extern "C" int vlg_gpt_session_prefill_batch(vlg_gpt_t* h, int32_t first_slot, int32_t n, const float* d_cond, const float* d_mask) {
   VLG_CHECK(h && d_cond, VLG_ERR_BAD_ARG, "vlg_gpt_session_prefill: null argument");
   VLG_CHECK(h->ses != nullptr, VLG_ERR_STATE, "no open session");
   VLG_CHECK(h->cfg.model_type == VLG_T2I || h->cfg.model_type == VLG_T2V, VLG_ERR_UNSUPPORTED, "vlg_gpt_session_prefill is for text-conditioned models");
-  VLG_CHECK(slot >= 0 && slot < h->ses->R, VLG_ERR_BAD_ARG, "slot %d out of range", slot);
-  return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, slot, d_cond, d_mask) : session_prefill_impl<float>(h, slot, d_cond, d_mask);
+  VLG_CHECK(n >= 1 && first_slot >= 0 && first_slot + n <= h->ses->R, VLG_ERR_BAD_ARG, "slots %d .. %d out of range", first_slot, first_slot + n - 1);
+  return h->dtype == VLG_BF16 ? session_prefill_impl<bf16>(h, first_slot, n, d_cond, d_mask) : session_prefill_impl<float>(h, first_slot, n, d_cond, d_mask);
+}
+
+extern "C" int vlg_gpt_session_prefill(vlg_gpt_t* h, int32_t slot, const float* d_cond, const float* d_mask) {
+  return vlg_gpt_session_prefill_batch(h, slot, 1, d_cond, d_mask);
 }
 
 extern "C" int vlg_gpt_set_option_f64(vlg_gpt_t* h, const char* key, double value) {

@@ -154,6 +154,8 @@ int build_text_cond(const float* cond, const T* uncond, T* out, int B, int Bp, i
 // rows (b, Tq-1) of x [Bp*Tq, D] -> [Bp, D]
 template <typename T>
 int take_last_rows(const T* x, T* out, int Bp, int Tq, int D, hipStream_t st);
+template <typename T>
+int drop_last_rows(const T* x, T* out, int Bp, int Tq, int D, hipStream_t st);   // [Bp][Tq][D] -> [Bp][Tq - 1][D]
 // latent fp32 [B,C] (cur) -> T [Bp, C] (duplicated for CFG)
 template <typename T>
 int latent_to_rows(const float* cur, T* out, int B, int Bp, int C, hipStream_t st);

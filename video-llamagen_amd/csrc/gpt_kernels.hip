@@ -1144,6 +1144,23 @@ int take_last_rows(const T* x, T* out, int Bp, int Tq, int D, hipStream_t st) {
 template int take_last_rows<float>(const float*, float*, int, int, int, hipStream_t);
 template int take_last_rows<bf16>(const bf16*, bf16*, int, int, int, hipStream_t);
 
+// x [Bp][Tq][D] -> out [Bp][Tq - 1][D]: every batch row without its last position (session prefill of several slots: the last condition
+// token is not run through the layers, it becomes the slot's first decode input)
+template <typename T>
+__global__ __launch_bounds__(256) void drop_last_rows_kernel(const T* __restrict__ x, T* __restrict__ out, int Tq, int D) {
+  const int b = blockIdx.y, t = blockIdx.x;   // t < Tq - 1
+  const T* src = x + ((size_t)b * Tq + t) * D;
+  T* dst = out + ((size_t)b * (Tq - 1) + t) * D;
+  for (int i = threadIdx.x; i < D; i += 256) dst[i] = src[i];
+}
+template <typename T>
+int drop_last_rows(const T* x, T* out, int Bp, int Tq, int D, hipStream_t st) {
+  if (Tq > 1) drop_last_rows_kernel<T><<<dim3(Tq - 1, Bp), 256, 0, st>>>(x, out, Tq, D);
+  return VLG_OK;
+}
+template int drop_last_rows<float>(const float*, float*, int, int, int, hipStream_t);
+template int drop_last_rows<bf16>(const bf16*, bf16*, int, int, int, hipStream_t);
+
 template <typename T>
 __global__ void latent_to_rows_kernel(const float* __restrict__ cur, T* __restrict__ out, int B, int Bp, int C) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

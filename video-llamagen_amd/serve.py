@@ -309,6 +309,25 @@ class ContinuousLLMEngine:
                 hit = True
         return hit
 
+    def _prefill(self, starts):
+        """Conditions of the requests admitted in this iteration into their slots' KV rows: runs of CONSECUTIVE slots go through one
+        vlg_gpt_session_prefill_batch call (one prefill of n x 119 rows instead of n of 119)."""
+        L, dev = self._L, self.model._device
+        runs, cur = [], [starts[0]]
+        for item in starts[1:]:
+            if item[0] == cur[-1][0] + 1 and (item[1].emb_mask is None) == (cur[0][1].emb_mask is None):
+                cur.append(item)
+            else:
+                runs.append(cur)
+                cur = [item]
+        runs.append(cur)
+        with torch.cuda.device(dev):
+            torch.cuda.current_stream(dev).synchronize()            # the features may come from another stream's work
+            for run in runs:
+                emb = torch.stack([r.prompt_embeds.to(device=dev, dtype=torch.float32) for _, r in run]).contiguous()
+                msk = None if run[0][1].emb_mask is None else torch.stack([r.emb_mask.to(device=dev, dtype=torch.float32) for _, r in run]).contiguous()
+                L.check(L.lib().vlg_gpt_session_prefill_batch(self.model._handle, run[0][0], len(run), L.ptr(emb), L.ptr(msk)))
+
     def close(self):
         if self._open:
             self._L.check(self._L.lib().vlg_gpt_session_end(self.model._handle))
@@ -323,6 +342,7 @@ class ContinuousLLMEngine:
         row_class = (C.c_int32 * self.slots_n)()
         grow = self.kv_policy == "grow"
         blocked = self._grow() if grow else False                   # growth first; after a preemption nobody is admitted in this iteration
+        starts = []                                                 # text-conditioned requests admitted in this iteration: (slot, request)
         # the head of the queue waits for KV blocks: nobody overtakes it (FIFO),
         for i, s in enumerate(self.slots):                          # but every later slot still gets its own code (-1 running, -2 idle)
             if s is not None:
@@ -343,12 +363,7 @@ class ContinuousLLMEngine:
                     continue
                 if self.text:
                     self.waiting.popleft()
-                    dev = self.model._device
-                    emb = r.prompt_embeds.to(device=dev, dtype=torch.float32).contiguous()
-                    msk = None if r.emb_mask is None else r.emb_mask.to(device=dev, dtype=torch.float32).contiguous()
-                    with torch.cuda.device(dev):
-                        torch.cuda.current_stream(dev).synchronize()        # the features may come from another stream's work
-                        L.check(L.lib().vlg_gpt_session_prefill(self.model._handle, i, L.ptr(emb), L.ptr(msk)))
+                    starts.append((i, r))                           # prefilled below, consecutive slots in one call
                     self.slots[i] = [r, 0, None]
                     row_class[i] = -3                               # first iteration: the last condition token, samples token 0
                     continue
@@ -360,6 +375,8 @@ class ContinuousLLMEngine:
             if self.waiting:
                 raise ValueError("classifier-free guidance needs one null-class prompt [[%s]] per conditional prompt" % self.null_token)
             return []
+        if starts:
+            self._prefill(starts)
         with torch.cuda.device(self.model._device):
             L.check(L.lib().vlg_gpt_session_step(self.model._handle, row_class))
         self.steps_run += 1
