@@ -1404,7 +1404,10 @@ struct vlg_gpt::Session {
   int R = 0, Rp = 0, S = 0, maxN = 0;
   bool cfg = false;
   vlg_sampling_params sp{};
-  DevBuf row_pos, row_step, row_cls, out_ids;
+  DevBuf row_all, out_ids;            // row_all: [3][Rp] int32 = per-row position | token index | start code, refreshed by ONE copy per iteration
+  int32_t* d_pos() const { return row_all.as<int32_t>(); }
+  int32_t* d_step() const { return row_all.as<int32_t>() + Rp; }
+  int32_t* d_cls() const { return row_all.as<int32_t>() + 2 * (size_t)Rp; }
   DevBuf out_lat;                     // continuous-latent models: [R][maxN][C] fp32 instead of out_ids
   DevBuf maskbuf, pending;            // text-conditioned models: [R][Tc] fp32 condition masks; [Rp][D] input rows of starting slots
   std::vector<char> prefilled;        // slot has a condition in its KV rows and waits for its first step
@@ -1474,12 +1477,9 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
     VLG_TRY(reserve_lane(h, ses->ln, R, ses->Rp, ses->S));
   }
   const size_t nb = (size_t)ses->Rp * sizeof(int32_t);
-  VLG_TRY(ses->row_pos.reserve(nb));
-  VLG_TRY(ses->row_step.reserve(nb));
-  VLG_TRY(ses->row_cls.reserve(nb));
+  VLG_TRY(ses->row_all.reserve(3 * nb));
   VLG_TRY(ses->out_ids.reserve((size_t)R * maxN * sizeof(int32_t)));
-  VLG_HIP(hipMemset(ses->row_pos.p, 0, nb));
-  VLG_HIP(hipMemset(ses->row_step.p, 0, nb));
+  VLG_HIP(hipMemset(ses->row_all.p, 0, 3 * nb));
   VLG_HIP(hipMemset(ses->ln.cur_tok.p, 0, (size_t)ses->Rp * sizeof(int32_t)));
   VLG_HIP(hipMemset(ses->out_ids.p, 0, (size_t)R * maxN * sizeof(int32_t)));
   if (h->cfg.model_type == VLG_T2V) {
@@ -1503,8 +1503,8 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   }
   VLG_TRY(set_state(ses->ln.state.as<StepState>(), 0, 0, st));
   Runner<T> r{h, &ses->ln, st, R, ses->Rp, maxN, ses->S, 0, R, text ? ses->maskbuf.as<float>() : nullptr};
-  r.row_pos = ses->row_pos.as<int32_t>();
-  r.row_step = ses->row_step.as<int32_t>();
+  r.row_pos = ses->d_pos();
+  r.row_step = ses->d_step();
   r.pending = ses->pending.p;
   r.pages = ses->pages();
   r.pool_blocks = ses->pool_blocks;
@@ -1518,7 +1518,7 @@ int session_begin_impl(vlg_gpt* h, int R, int maxN, const vlg_sampling_params& s
   if (h->use_graph) {
     VLG_HIP(hipStreamSynchronize(st));
     VLG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = r.session_step(ses->sp, ses->row_cls.as<int32_t>(), ses->out_ids.as<int32_t>(), ses->out_lat.as<float>());
+    const int rc = r.session_step(ses->sp, ses->d_cls(), ses->out_ids.as<int32_t>(), ses->out_lat.as<float>());
     hipError_t ee = hipStreamEndCapture(st, &ses->graph);
     VLG_TRY(rc);
     VLG_HIP(ee);
@@ -1597,9 +1597,7 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
   memcpy(stg, s.h_pos.data(), nb);
   memcpy(stg + s.Rp, s.h_step.data(), nb);
   memcpy(stg + 2 * (size_t)s.Rp, s.h_cls.data(), nb);
-  VLG_HIP(hipMemcpyAsync(s.row_pos.p, stg, nb, hipMemcpyHostToDevice, st));
-  VLG_HIP(hipMemcpyAsync(s.row_step.p, stg + s.Rp, nb, hipMemcpyHostToDevice, st));
-  VLG_HIP(hipMemcpyAsync(s.row_cls.p, stg + 2 * (size_t)s.Rp, nb, hipMemcpyHostToDevice, st));
+  VLG_HIP(hipMemcpyAsync(s.row_all.p, stg, 3 * nb, hipMemcpyHostToDevice, st));   // one copy: the three arrays sit side by side on both ends
   VLG_HIP(hipEventRecord(s.ev_stage[slot], st));
   s.stage_used[slot] = true;
   s.stage_i += 1;
@@ -1635,12 +1633,12 @@ int session_step_impl(vlg_gpt* h, const int32_t* h_row_class) {
     VLG_HIP(hipGraphLaunch(s.exec, st));
   } else {
     Runner<T> r{h, &s.ln, st, R, s.Rp, s.maxN, s.S, 0, R, text ? s.maskbuf.as<float>() : nullptr};
-    r.row_pos = s.row_pos.as<int32_t>();
-    r.row_step = s.row_step.as<int32_t>();
+    r.row_pos = s.d_pos();
+    r.row_step = s.d_step();
     r.pending = s.pending.p;
     r.pages = s.pages();
     r.pool_blocks = s.pool_blocks;
-    VLG_TRY(r.session_step(s.sp, s.row_cls.as<int32_t>(), s.out_ids.as<int32_t>(), s.out_lat.as<float>()));
+    VLG_TRY(r.session_step(s.sp, s.d_cls(), s.out_ids.as<int32_t>(), s.out_lat.as<float>()));
   }
   // the iteration is enqueued; its inputs sit in a pinned staging slot of their own, so the host may go on (session_read / session_end wait
   // for the stream, everything else a caller does with the session is ordered behind it on the same stream)
