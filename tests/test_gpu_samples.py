@@ -443,6 +443,35 @@ def test_t2v_diffloss_sessions_match_generate():
     m.dl_persist = True
 
 
+@pytest.mark.parametrize("slots", [8, 34])
+def test_t2v_diffloss_sessions_full_width_bf16(slots):
+    """The benchmark's DiffLoss head (W 1024, depth 3, 100 reverse steps, bf16) inside a session: 8 slots = groups of four rows, 34 slots = the
+    eight-row groups (dl_persist_kernel<bf16, 2, true, 3, 8> with per-row token indices).  All slots start together, so every request must
+    reproduce its row of generate_t2v(seed) - same kernels, same noise keys; bf16 tolerance on the first token, finite throughout."""
+    import video_llamagen_amd as V
+    from vlg_testutil import to_np
+    m = V.Transformer(V.ModelArgs(dim=256, n_layer=2, n_head=4, block_size=64, cls_token_num=8, model_type="t2v", vae_embed_dim=8,
+                                  num_frames=17, t_downsample_size=4, caption_dim=64, head="hidden", diffloss_w=1024, diffloss_d=3,
+                                  num_sampling_steps=100)).to("cuda", torch.bfloat16)
+    m.init_random_weights(seed=4)
+    g = torch.Generator().manual_seed(2)
+    cond = torch.randn(slots, 8, 64, generator=g) * 0.1
+    mask = torch.ones(slots, 8)
+    N = 3
+    sp = V.SamplingParams(temperature=1.0, max_tokens=N, seed=11)
+    eng = V.ContinuousLLMEngine(m, max_num_seqs=slots)
+    for i in range(slots):
+        eng.add_request(str(i), None, sp, prompt_embeds=cond[i], emb_mask=mask[i])
+    outs = {}
+    while eng.has_unfinished_requests():
+        for o in eng.step():
+            outs[int(o.request_id)] = to_np(o.outputs[0].latents)
+    got = np.stack([outs[i] for i in range(slots)])
+    ref = to_np(V.generate_t2v(m, cond, N, mask, temperature=1.0, seed=11))
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert np.abs(got[:, 0] - ref[:, 0]).max() < 8e-2 * max(1.0, np.abs(ref[:, 0]).max())
+
+
 def test_block_granular_kv_is_the_same_arithmetic():
     """Paging only changes where a cache row lives: sampled (top-k, temperature 1, guidance) bf16 sessions produce the same ids on 16-position
     blocks handed out of a tight pool as on contiguous slots."""
